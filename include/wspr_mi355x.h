@@ -1,0 +1,163 @@
+/* ============================================================================
+ * wspr_mi355x.h -- C ABI of libwspr_mi355x.so, the MI355X-native WSPR decoder.
+ *
+ * Drop-in boundary for Guenael/rtlsdr-wsprd v0.5.6: the library exports the
+ * reference decoder's own entry point and spot struct, so rtlsdr_wsprd.c can be
+ * linked against it instead of wsprd/wsprd.c.  Plain C
+ * types only; device pointers are passed as void*.
+ *
+ * Every declaration cites the reference interface it replaces.
+ * ==========================================================================*/
+#ifndef WSPR_MI355X_H
+#define WSPR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants the caller uses (reference wsprd/wsprd.h:36-41) ------------ */
+#define HASHTAB_SIZE       32768
+#define HASHTAB_ENTRY_LEN  13
+#define LOCTAB_ENTRY_LEN   5
+#define FFT_SIZE           512
+#define MAX_CANDIDATES     200
+#define MAX_UNIQUES        100
+
+/* ---- structs, identical layout (reference wsprd/wsprd.h:44-74) ------------ */
+struct decoder_options {            /* 40 bytes, passed BY VALUE */
+    int  freq;                      /* dial frequency, Hz */
+    char rcall[13];
+    char rloc[7];
+    int  quickmode;
+    int  usehashtable;
+    int  npasses;
+    int  subtraction;
+};
+
+struct cand {                       /* 20 bytes */
+    float freq;
+    float snr;
+    int   shift;
+    float drift;
+    float sync;
+};
+
+struct decoder_results {            /* 80 bytes: the spot record */
+    double freq;
+    float  sync;
+    float  snr;
+    float  dt;
+    float  drift;
+    int    jitter;
+    char   message[23];
+    char   call[13];
+    char   loc[7];
+    char   pwr[3];
+    int    cycles;
+};
+
+/* ---- THE BOUNDARY --------------------------------------------------------- */
+/* Replaces wspr_decode(), reference wsprd/wsprd.h:106-111 / wsprd/wsprd.c:416.
+ * Same contract: idat/qdat (length `samples`, <= 45000) are overwritten with the
+ * residual after coherent subtraction, decodes[0..*n_results) is filled strongest
+ * first, returns 0.  One call = a batch of one segment on the GPU.
+ * hashtable.txt / fftw_wisdom.dat side effects of the reference are not kept. */
+int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options options,
+                struct decoder_results *decodes, int *n_results);
+
+/* Batched form of the same call (build-defined): nseg independent
+ * segments, planar host buffers idat/qdat[s*seg_stride + i]; results for segment s
+ * go to decodes[s*max_results ...], n_results[s].  Inputs are not modified unless
+ * writeback != 0. */
+int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
+                      struct decoder_options options, struct decoder_results *decodes,
+                      int max_results, int *n_results, int writeback);
+
+/* Same, with the IQ already resident in HBM (device pointers, same layout).
+ * The input is copied to a working buffer and left untouched.  This is the
+ * entry point bench.py times. */
+int wspr_decode_batch_device(const void *d_idat, const void *d_qdat, int nseg, int samples,
+                             size_t seg_stride, struct decoder_options options,
+                             struct decoder_results *decodes, int max_results, int *n_results);
+
+/* Front end, replaces the static rtlsdr_callback() + decoder() normalisation
+ * (reference rtlsdr_wsprd.c:126-244, :284-305).  iq = interleaved unsigned 8-bit
+ * I/Q at 2.4 Msps, nbytes a multiple of 8, decimator state zero at the start.
+ * Writes min(floor(nbytes/2/6401), 45000) samples to I/Q (capacity 45000 each;
+ * the rest is zero-filled when normalise != 0, which also scales to peak 0.5). */
+int wspr_decimate_u8(const uint8_t *iq, size_t nbytes, float *I, float *Q, uint32_t *n_out,
+                     int normalise);
+/* nseg raw segments resident in HBM -> planar float IQ in HBM (rows of
+ * wspr_iq_stride() floats), normalised, ready for wspr_decode_batch_device. */
+int wspr_decimate_u8_batch_device(const void *d_raw, size_t bytes_per_seg, int nseg,
+                                  void *d_idat, void *d_qdat, int normalise);
+size_t wspr_iq_stride(void);        /* floats per segment row of device IQ buffers */
+
+/* ---- kernel-level entry points (parity tests and profiling) --------------- */
+/* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed). */
+void sync_and_demodulate(float *id, float *qd, long np, unsigned char *symbols, float *freq,
+                         int ifmin, int ifmax, float fstep, int *shift, int lagmin, int lagmax,
+                         int lagstep, float *drift, int symfac, float *sync, int mode);
+/* Replaces subtract_signal2(), reference wsprd/wsprd.h:99-105 (GPU-backed). */
+void subtract_signal2(float *id, float *qd, long np, float f0, int shift, float drift,
+                      const unsigned char *channel_symbols);
+/* FFT bank + power spectrogram (reference wsprd/wsprd.c:509-553) for nseg host
+ * segments; ps_out[s][bin 0..511][t 0..blocks) in the reference's bin-major
+ * layout, bins outside 48..464 are zero. */
+int wspr_stage_fft_bank(const float *idat, const float *qdat, int nseg, int samples,
+                        size_t seg_stride, float *ps_out);
+/* Peak picker + coarse sync (reference wsprd/wsprd.c:555-678) for nseg host
+ * segments: cand_out[s][200] strongest first (after coarse sync when coarse != 0),
+ * npk_out[s], noise_out[s] (may be NULL), smspec_out[s][411] (may be NULL). */
+int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int samples,
+                          size_t seg_stride, int coarse, int maxdrift, struct cand *cand_out,
+                          int *npk_out, float *noise_out, float *smspec_out);
+/* Timing of the stages of the most recent batch call, milliseconds (HIP events on
+ * the library's stream). Order: fft_bank, pick_peaks, coarse_sync, demod, subtract,
+ * host_fano, total. Returns the number of values written. */
+int wspr_last_timings(double *ms, int capacity);
+/* Times `iters` back-to-back launches of the FFT+sync stage (K1,K2,K3) on resident
+ * data with HIP events; returns average ms per launch of each kernel in ms[0..2]. */
+int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
+                        size_t seg_stride, int iters, double *ms);
+/* Library / device description, e.g. for bench logs. */
+const char *wspr_mi355x_version(void);
+int wspr_device_ready(void);        /* 1 if a HIP device and the kernels are usable */
+
+/* ---- message layer, same names as the reference exports ------------------- */
+/* reference wsprd/wsprsim_utils.h:1-9 */
+char get_locator_character_code(char ch);
+char get_callsign_character_code(char ch);
+long unsigned int pack_grid4_power(char const *grid4, int power);
+long unsigned int pack_call(char const *callsign);
+void pack_prefix(char *callsign, int32_t *n, int32_t *m, int32_t *nadd);
+void interleave(unsigned char *sym);
+int  get_wspr_channel_symbols(char *message, char *hashtab, char *loctab, unsigned char *symbols);
+/* reference wsprd/wsprd_utils.h:32-42 */
+void unpack50(signed char *dat, int32_t *n1, int32_t *n2);
+int  unpackcall(int32_t ncall, char *call);
+int  unpackgrid(int32_t ngrid, char *grid);
+int  unpackpfx(int32_t nprefix, char *call);
+void deinterleave(unsigned char *sym);
+int  doublecomp(const void *elem1, const void *elem2);
+int  floatcomp(const void *elem1, const void *elem2);
+int  unpk_(signed char *message, char *hashtab, char *loctab, char *call_loc_pow, char *call,
+           char *loc, char *pwr, char *callsign);
+/* reference wsprd/fano.h:14-28 */
+int  fano(unsigned int *metric, unsigned int *cycles, unsigned int *maxnp, unsigned char *data,
+          unsigned char *symbols, unsigned int nbits, int mettab[2][256], int delta,
+          unsigned int maxcycles);
+int  encode(unsigned char *symbols, unsigned char *data, unsigned int nbytes);
+extern unsigned char Partab[];
+/* reference wsprd/nhash.h:3 */
+uint32_t nhash(const void *key, size_t length, uint32_t initval);
+/* the integer branch-metric table wspr_decode derives at wsprd/wsprd.c:467-473 */
+void wspr_fano_metric_table(int mettab[2][256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSPR_MI355X_H */

@@ -1,0 +1,226 @@
+// C ABI of libwspr_mi355x.so (declared in include/wspr_mi355x.h).
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <vector>
+
+#include "wspr_message.h"
+#include "wspr_pipeline.h"
+
+using wspr::Context;
+
+namespace {
+// The reference reports nothing but "zero spots" on failure (wsprd.c:854 returns 0
+// always).  A missing GPU is a deployment error, not a weak-signal condition: say so
+// loudly on stderr and return a negative code; there is no CPU fallback.
+int fail(const char* where, const std::exception& e) {
+    fprintf(stderr, "libwspr_mi355x: %s failed: %s\n", where, e.what());
+    return -1;
+}
+}  // namespace
+
+extern "C" {
+
+const char* wspr_mi355x_version(void) { return "wspr-mi355x 0.1 (gfx950, HIP)"; }
+
+int wspr_device_ready(void) {
+    try { Context::get(); return 1; } catch (const std::exception& e) { fail("wspr_device_ready", e); return 0; }
+}
+
+size_t wspr_iq_stride(void) { return (size_t)wspr::kIqStride; }
+
+int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
+                      struct decoder_options options, struct decoder_results* decodes, int max_results,
+                      int* n_results, int writeback) {
+    try {
+        Context& c = Context::get();
+        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        c.load_host(idat, qdat, nseg, samples, seg_stride);
+        const int rc = c.decode_resident(nseg, samples, options, decodes, max_results, n_results);
+        if (writeback) c.store_host(idat, qdat, nseg, samples, seg_stride);
+        return rc;
+    } catch (const std::exception& e) {
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return fail("wspr_decode_batch", e);
+    }
+}
+
+int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
+                             struct decoder_options options, struct decoder_results* decodes, int max_results,
+                             int* n_results) {
+    try {
+        Context& c = Context::get();
+        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
+        return c.decode_resident(nseg, samples, options, decodes, max_results, n_results);
+    } catch (const std::exception& e) {
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return fail("wspr_decode_batch_device", e);
+    }
+}
+
+int wspr_decode(float* idat, float* qdat, int samples, struct decoder_options options,
+                struct decoder_results* decodes, int* n_results) {
+    // the reference caller owns decodes[] with room for its own count (50 in rtlsdr_wsprd.c:117)
+    std::vector<decoder_results> tmp(MAX_UNIQUES);
+    int n = 0;
+    const int rc = wspr_decode_batch(idat, qdat, 1, samples, (size_t)samples, options, tmp.data(), MAX_UNIQUES, &n, 1);
+    for (int i = 0; i < n; ++i) decodes[i] = tmp[i];
+    *n_results = n;
+    return rc < 0 ? rc : 0;
+}
+
+void sync_and_demodulate(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin, int ifmax,
+                         float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, int symfac,
+                         float* sync, int mode) {
+    (void)symfac;   // the decoder only ever uses 50 (wsprd.c:427); the kernel has it built in
+    try {
+        Context::get().demod_single(id, qd, np, symbols, freq, ifmin, ifmax, fstep, shift, lagmin, lagmax, lagstep,
+                                    drift, sync, mode);
+    } catch (const std::exception& e) { fail("sync_and_demodulate", e); }
+}
+
+void subtract_signal2(float* id, float* qd, long np, float f0, int shift, float drift,
+                      const unsigned char* channel_symbols) {
+    try { Context::get().subtract_single(id, qd, np, f0, shift, drift, channel_symbols); }
+    catch (const std::exception& e) { fail("subtract_signal2", e); }
+}
+
+int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
+                        float* ps_out) {
+    try {
+        Context& c = Context::get();
+        const int blocks = 4 * (samples / wspr::kFftSize) - 1;
+        c.load_host(idat, qdat, nseg, samples, seg_stride);
+        float* ps = c.ps_buffer(nseg);
+        wspr::launch_fft_bank(c.work_i(nseg), c.work_q(nseg), nullptr, nseg, samples, ps, c.tables(), c.stream());
+        std::vector<float> h((size_t)nseg * wspr::kMaxBlocks * wspr::kPsStride);
+        if (hipMemcpyAsync(h.data(), ps, h.size() * 4, hipMemcpyDeviceToHost, c.stream()) != hipSuccess) return -1;
+        c.sync();
+        memset(ps_out, 0, (size_t)nseg * wspr::kFftSize * blocks * sizeof(float));
+        for (int s = 0; s < nseg; ++s)
+            for (int t = 0; t < blocks; ++t)
+                for (int b = 0; b < wspr::kPsBins; ++b)
+                    ps_out[((size_t)s * wspr::kFftSize + (b + wspr::kPsBin0)) * blocks + t] =
+                        h[((size_t)s * wspr::kMaxBlocks + t) * wspr::kPsStride + b];
+        return blocks;
+    } catch (const std::exception& e) { return fail("wspr_stage_fft_bank", e); }
+}
+
+int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
+                          int coarse, int maxdrift, struct cand* cand_out, int* npk_out, float* noise_out,
+                          float* smspec_out) {
+    try {
+        Context& c = Context::get();
+        c.load_host(idat, qdat, nseg, samples, seg_stride);
+        float *d_noise = nullptr, *d_sm = nullptr;
+        if (hipMalloc(&d_noise, (size_t)nseg * 4) != hipSuccess) return -1;
+        if (hipMalloc(&d_sm, (size_t)nseg * wspr::kSmooth * 4) != hipSuccess) return -1;
+        c.run_fft_sync(nseg, samples, maxdrift, coarse != 0, nullptr, nseg, d_noise, d_sm);
+        std::vector<int> npk;
+        std::vector<wspr::DevCand> cd;
+        c.fetch_candidates(nseg, npk, cd);
+        if (noise_out) hipMemcpy(noise_out, d_noise, (size_t)nseg * 4, hipMemcpyDeviceToHost);
+        if (smspec_out) hipMemcpy(smspec_out, d_sm, (size_t)nseg * wspr::kSmooth * 4, hipMemcpyDeviceToHost);
+        hipFree(d_noise);
+        hipFree(d_sm);
+        for (int s = 0; s < nseg; ++s) {
+            npk_out[s] = npk[s];
+            for (int j = 0; j < wspr::kMaxCand; ++j) {
+                struct cand o = {0, 0, 0, 0, 0};
+                if (j < npk[s]) {
+                    const wspr::DevCand& v = cd[(size_t)s * wspr::kMaxCand + j];
+                    o.freq = v.freq; o.snr = v.snr; o.shift = v.shift; o.drift = v.drift; o.sync = v.sync;
+                }
+                cand_out[(size_t)s * wspr::kMaxCand + j] = o;
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_stage_candidates", e); }
+}
+
+int wspr_last_timings(double* ms, int capacity) {
+    try { return Context::get().last_timings(ms, capacity); } catch (const std::exception& e) { return fail("wspr_last_timings", e); }
+}
+
+int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,
+                        double* ms) {
+    try {
+        Context& c = Context::get();
+        c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
+        return c.bench_fft_sync(nseg, samples, iters, ms);
+    } catch (const std::exception& e) { return fail("wspr_bench_fft_sync", e); }
+}
+
+int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
+                                  int normalise) {
+    try {
+        return Context::get().decimate_device(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, normalise, nullptr);
+    } catch (const std::exception& e) { return fail("wspr_decimate_u8_batch_device", e); }
+}
+
+int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t* n_out, int normalise) {
+    try {
+        Context& c = Context::get();
+        nbytes &= ~(size_t)7;
+        void* d_raw = nullptr;
+        if (hipMalloc(&d_raw, nbytes + 16) != hipSuccess) return -1;
+        hipMemcpy(d_raw, iq, nbytes, hipMemcpyHostToDevice);
+        float* wi = c.work_i(1);
+        float* wq = c.work_q(1);
+        int nout = 0;
+        const int rc = c.decimate_device(d_raw, nbytes, 1, wi, wq, normalise, &nout);
+        hipFree(d_raw);
+        if (rc) return rc;
+        hipMemcpy(I, wi, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(Q, wq, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost);
+        if (n_out) *n_out = (uint32_t)nout;
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_decimate_u8", e); }
+}
+
+// ---- message layer under the reference's names ---------------------------------
+char get_locator_character_code(char ch) { return wspr::locator_code(ch); }
+char get_callsign_character_code(char ch) { return wspr::callsign_code(ch); }
+long unsigned int pack_grid4_power(char const* grid4, int power) { return wspr::pack_grid_power(grid4, power); }
+long unsigned int pack_call(char const* callsign) { return wspr::pack_callsign(callsign); }
+void pack_prefix(char* callsign, int32_t* n, int32_t* m, int32_t* nadd) { wspr::pack_compound(callsign, n, m, nadd); }
+void interleave(unsigned char* sym) { wspr::interleave162(sym); }
+void deinterleave(unsigned char* sym) { wspr::deinterleave162(sym); }
+int get_wspr_channel_symbols(char* message, char* hashtab, char* loctab, unsigned char* symbols) {
+    return wspr::channel_symbols(message, hashtab, loctab, symbols);
+}
+void unpack50(signed char* dat, int32_t* n1, int32_t* n2) { wspr::unpack_50bits(dat, n1, n2); }
+int unpackcall(int32_t ncall, char* call) { return wspr::unpack_callsign(ncall, call); }
+int unpackgrid(int32_t ngrid, char* grid) { return wspr::unpack_grid(ngrid, grid); }
+int unpackpfx(int32_t nprefix, char* call) { return wspr::unpack_prefix(nprefix, call); }
+int unpk_(signed char* message, char* hashtab, char* loctab, char* call_loc_pow, char* call, char* loc, char* pwr,
+          char* callsign) {
+    return wspr::unpack_message(message, hashtab, loctab, call_loc_pow, call, loc, pwr, callsign);
+}
+int fano(unsigned int* metric, unsigned int* cycles, unsigned int* maxnp, unsigned char* data,
+         unsigned char* symbols, unsigned int nbits, int mettab[2][256], int delta, unsigned int maxcycles) {
+    return wspr::fano_decode(metric, cycles, maxnp, data, symbols, nbits, mettab, delta, maxcycles);
+}
+int encode(unsigned char* symbols, unsigned char* data, unsigned int nbytes) {
+    return wspr::conv_encode(symbols, data, nbytes);
+}
+uint32_t nhash(const void* key, size_t length, uint32_t initval) { return wspr::nhash15(key, length, initval); }
+void wspr_fano_metric_table(int mettab[2][256]) {
+    memcpy(mettab, wspr::default_metrics().tab, sizeof(int) * 512);
+}
+int doublecomp(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return x < y ? -1 : (x > y);
+}
+int floatcomp(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return x < y ? -1 : (x > y);
+}
+// 8-bit parity table (reference wsprd/tab.c:7), generated
+unsigned char Partab[256];
+__attribute__((constructor)) static void partab_init(void) {
+    for (int i = 0; i < 256; ++i) Partab[i] = (unsigned char)__builtin_parity((unsigned)i);
+}
+
+}  // extern "C"

@@ -1,0 +1,694 @@
+// Host scheduler of the MI355X WSPR decoder: owns the HIP stream, the resident
+// buffers and the host Fano pool, and drives the kernels of csrc/kernels/ so that
+// a batch of independent 2-minute segments is decoded with the reference's
+// semantics (wsprd/wsprd.c:416-855), including its sequential ones:
+//   * pass 0 visits a segment's candidates strongest first and every successful
+//     decode is subtracted from that segment's IQ before the next candidate is
+//     refined -> candidates are processed in lock-step "ranks" across segments;
+//   * pass 1 (and any pass without subtraction) has no such dependence -> all
+//     (segment, candidate) pairs go through the GPU in one wave, and only the
+//     host bookkeeping (hash table, de-duplication, early loop exits) is ordered;
+//   * the jitter ladder stops at the first Fano success -> jitter 0 is demodulated
+//     for everybody, the remaining 42 steps only for the candidates that need them.
+// The Fano decoder, message unpacking and re-encoding stay on the host (north star).
+#include "wspr_pipeline.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "wspr_message.h"
+
+namespace wspr {
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) +   \
+                                     " at " #expr);                                          \
+    } while (0)
+
+// ------------------------------------------------------------------ buffers --
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIP_OK(hipFree(p));
+            p = nullptr;
+            size_t want = bytes + bytes / 4;
+            HIP_OK(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIP_OK(hipHostFree(p));
+            p = nullptr;
+            size_t want = bytes + bytes / 4;
+            HIP_OK(hipHostMalloc(&p, want, hipHostMallocDefault));
+            cap = want;
+        }
+        return p;
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------- thread pool --
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; ++epoch_; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // runs fn(i) for i in [0, n); the calling thread participates
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (workers_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn; total_ = n; next_.store(0); pending_ = (int)workers_.size(); ++epoch_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    int size() const { return (int)workers_.size() + 1; }
+
+private:
+    void drain() {
+        for (;;) {
+            int i = next_.fetch_add(1);
+            if (i >= total_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (quit_) return;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int total_ = 0, pending_ = 0;
+    unsigned long epoch_ = 0;
+    bool quit_ = false;
+};
+
+// ---------------------------------------------------------------- context ----
+struct Context::Impl {
+    hipStream_t stream = nullptr;
+    DeviceTables tab{};
+    DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
+    DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
+        nvalid, decscratch;
+    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc;
+    std::unique_ptr<Pool> pool;
+    int jitter_ladder[kMaxLags];
+    // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
+    char* hash_arena = nullptr;
+    size_t hash_arena_segs = 0;
+    double t_ms[8] = {0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+static void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+}
+
+Context::Context() : d(new Impl) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
+    HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&d->ev[0]));
+    HIP_OK(hipEventCreate(&d->ev[1]));
+
+    // constant tables, computed with the host libm exactly as the reference does
+    std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
+    for (int j = 0; j < kFftSize; ++j) window[j] = sinf(0.006147931 * j);          // wsprd.c:509-513
+    std::vector<float2> tw(256);
+    for (int k = 0; k < 256; ++k) {
+        const double a = 2.0 * M_PI * (double)k / 512.0;
+        tw[k] = make_float2((float)cos(a), (float)(-sin(a)));
+    }
+    tw[0] = make_float2(1.0f, 0.0f);
+    tw[128] = make_float2(0.0f, -1.0f);
+    float norm = 0.0f;                                                               // wsprd.c:353-368
+    for (int i = 0; i < kLpfTaps; ++i) { lpf[i] = sinf(M_PI * (float)i / (float)(kLpfTaps - 1)); norm = norm + lpf[i]; }
+    for (int i = 0; i < kLpfTaps; ++i) lpf[i] = lpf[i] / norm;
+    part[0] = 0.0f;
+    for (int i = 1; i < kLpfTaps; ++i) part[i] = part[i - 1] + lpf[i];
+    for (int idt = 0; idt < kMaxLags; ++idt) {                                       // wsprd.c:742-744
+        int ii = (idt + 1) / 2;
+        if (idt % 2 == 1) ii = -ii;
+        d->jitter_ladder[idt] = 3 * ii;
+    }
+    upload(d->t_window.need(window.size() * 4), window.data(), window.size() * 4, d->stream);
+    upload(d->t_twiddle.need(tw.size() * 8), tw.data(), tw.size() * 8, d->stream);
+    upload(d->t_sync.need(kNSym), sync_vector(), kNSym, d->stream);
+    upload(d->t_lpf.need(lpf.size() * 4), lpf.data(), lpf.size() * 4, d->stream);
+    upload(d->t_part.need(part.size() * 4), part.data(), part.size() * 4, d->stream);
+    upload(d->t_jitter.need(sizeof d->jitter_ladder), d->jitter_ladder, sizeof d->jitter_ladder, d->stream);
+    HIP_OK(hipStreamSynchronize(d->stream));
+    d->tab.window = d->t_window.as<float>();
+    d->tab.twiddle = d->t_twiddle.as<float2>();
+    d->tab.sync = d->t_sync.as<unsigned char>();
+    d->tab.lpf = d->t_lpf.as<float>();
+    d->tab.lpf_part = d->t_part.as<float>();
+    d->tab.min_snr = powf(10.0, -8.0 / 10.0);                                        // wsprd.c:590
+    d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
+
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
+    nthreads = std::max(1, std::min(nthreads, 128));
+    d->pool.reset(new Pool(nthreads - 1));
+}
+
+Context::~Context() {}
+
+Context& Context::get() {
+    static Context ctx;
+    return ctx;
+}
+
+hipStream_t Context::stream() { return d->stream; }
+const DeviceTables& Context::tables() { return d->tab; }
+int Context::host_threads() { return d->pool->size(); }
+
+float* Context::work_i(int nseg) { return static_cast<float*>(d->iqI.need((size_t)nseg * kIqStride * 4)); }
+float* Context::work_q(int nseg) { return static_cast<float*>(d->iqQ.need((size_t)nseg * kIqStride * 4)); }
+
+// rows are kIqStride floats; everything past `samples` must read as zero (the FFT bank
+// of the reference reads up to 512*floor(samples/512)+255, wsprd.c:536-542)
+static void zero_tail(float* wi, float* wq, int nseg, int samples, hipStream_t st) {
+    const size_t tail = (size_t)(kIqStride - samples) * 4;
+    HIP_OK(hipMemset2DAsync(wi + samples, (size_t)kIqStride * 4, 0, tail, nseg, st));
+    HIP_OK(hipMemset2DAsync(wq + samples, (size_t)kIqStride * 4, 0, tail, nseg, st));
+}
+
+void Context::load_host(const float* I, const float* Q, int nseg, int samples, size_t stride) {
+    float* wi = work_i(nseg);
+    float* wq = work_q(nseg);
+    zero_tail(wi, wq, nseg, samples, d->stream);
+    HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, d->stream));
+    HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, d->stream));
+}
+void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {
+    float* wi = work_i(nseg);
+    float* wq = work_q(nseg);
+    zero_tail(wi, wq, nseg, samples, d->stream);
+    HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, dI, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));
+    HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, dQ, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));
+}
+void Context::store_host(float* I, float* Q, int nseg, int samples, size_t stride) {
+    HIP_OK(hipMemcpy2DAsync(I, stride * 4, d->iqI.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
+    HIP_OK(hipMemcpy2DAsync(Q, stride * 4, d->iqQ.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
+    HIP_OK(hipStreamSynchronize(d->stream));
+}
+void Context::sync() { HIP_OK(hipStreamSynchronize(d->stream)); }
+
+float* Context::ps_buffer(int nseg) {
+    return static_cast<float*>(d->ps.need((size_t)nseg * kMaxBlocks * kPsStride * 4));
+}
+
+// ---------------------------------------------------------------- stages -----
+void Context::run_fft_sync(int nseg, int samples, int maxdrift, bool coarse, const int* d_seglist, int nactive,
+                           float* noise_out, float* smspec_out) {
+    const int blocks = 4 * (samples / kFftSize) - 1;
+    float* ps = ps_buffer(nseg);
+    DevCand* cand = static_cast<DevCand*>(d->cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
+    int* npk = static_cast<int*>(d->npk.need((size_t)nseg * 4));
+    launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), d_seglist, nactive, samples, ps, d->tab, d->stream);
+    launch_pick_peaks(ps, d_seglist, nactive, blocks, cand, npk, noise_out, smspec_out, d->tab, d->stream);
+    if (coarse) launch_coarse_sync(ps, d_seglist, nactive, blocks, cand, npk, maxdrift, d->tab, d->stream);
+}
+
+void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
+    npk.resize(nseg);
+    cand.resize((size_t)nseg * kMaxCand);
+    HIP_OK(hipMemcpyAsync(npk.data(), d->npk.p, (size_t)nseg * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_OK(hipMemcpyAsync(cand.data(), d->cand.p, (size_t)nseg * kMaxCand * sizeof(DevCand), hipMemcpyDeviceToHost, d->stream));
+    HIP_OK(hipStreamSynchronize(d->stream));
+}
+
+// ---------------------------------------------------------------- decoding ---
+namespace {
+
+struct SegBook {                 // host bookkeeping of one segment across passes
+    int   uniques = 0;
+    float allfreqs[100];
+    char  allcalls[100][13];
+    std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
+};
+
+struct WaveItem {
+    int seg, cand;
+    // filled by the GPU wave
+    FineState fine;
+    bool worth = false, decoded = false;
+    int  jitter = 0;
+    unsigned cycles = 0;
+    unsigned char decdata[11];
+};
+
+struct Timer {
+    hipEvent_t a, b;
+    hipStream_t st;
+    double* acc;
+    Timer(hipEvent_t a_, hipEvent_t b_, hipStream_t s, double* acc_) : a(a_), b(b_), st(s), acc(acc_) {
+        hipEventRecord(a, st);
+    }
+    void stop() {
+        hipEventRecord(b, st);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        *acc += ms;
+    }
+};
+
+}  // namespace
+
+int Context::decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
+                             int max_results, int* n_results) {
+    Impl& c = *d;
+    for (double& v : c.t_ms) v = 0.0;
+    const auto t_all0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+    const int blocks = 4 * (samples / kFftSize) - 1;
+    if (nseg <= 0) return 0;
+    if (samples > kMaxSamples || blocks < 23) return 0;      // outside what the reference arrays allow
+
+    // tuning constants of wsprd.c:423-433
+    const float minsync1 = 0.10f;
+    float minsync2 = 0.12f;
+    int maxdrift = 4;
+    const float minrms = 52.0 * (50 / 64.0);
+    const int delta = 60;
+    const unsigned maxcycles = 10000;
+    const int lagstep = opt.quickmode ? 16 : 8;
+    const int nlag0 = 256 / lagstep + 1;
+    const int njit_rest = opt.quickmode ? 0 : kMaxLags - 1;
+    const FanoMetrics& met = default_metrics();
+
+    // per-segment hash memory: one zeroed table pair per segment, reused across batches
+    const size_t per_seg = (size_t)kHashSlots * (kHashWidth + kLocWidth);
+    if (c.hash_arena_segs < (size_t)nseg) {
+        free(c.hash_arena);
+        c.hash_arena = static_cast<char*>(calloc((size_t)nseg, per_seg));
+        if (!c.hash_arena) throw std::runtime_error("out of host memory for hash tables");
+        c.hash_arena_segs = (size_t)nseg;
+    }
+    auto hashtab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg; };
+    auto loctab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg + (size_t)kHashSlots * kHashWidth; };
+
+    std::vector<SegBook> book(nseg);
+    std::vector<int> npk;
+    std::vector<DevCand> cand;
+    std::vector<int> active(nseg);
+    for (int s = 0; s < nseg; ++s) active[s] = s;
+
+    for (int ipass = 0; ipass < opt.npasses; ++ipass) {
+        if (ipass == 1) {                                      // wsprd.c:522-523
+            std::vector<int> keep;
+            for (int s : active) if (book[s].uniques > 0) keep.push_back(s);
+            active.swap(keep);
+        }
+        if (active.empty()) break;
+        if (ipass < 2) { maxdrift = 4; minsync2 = 0.12f; }
+        if (ipass == 2) { maxdrift = 0; minsync2 = 0.10f; }
+
+        // ---- FFT bank, peaks, coarse sync for the active segments -----------
+        const int nact = (int)active.size();
+        int* d_seglist = nullptr;
+        if (nact != nseg) {
+            int* h = static_cast<int*>(c.h_seglist.need((size_t)nact * 4));
+            memcpy(h, active.data(), (size_t)nact * 4);
+            d_seglist = static_cast<int*>(c.seglist.need((size_t)nact * 4));
+            upload(d_seglist, h, (size_t)nact * 4, c.stream);
+        }
+        {
+            Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[0]);
+            run_fft_sync(nseg, samples, maxdrift, true, d_seglist, nact, nullptr, nullptr);
+            t.stop();
+        }
+        fetch_candidates(nseg, npk, cand);
+
+        const bool lockstep = opt.subtraction && ipass == 0;
+        std::vector<char> stopped(nseg, 0);
+        int max_npk = 0;
+        for (int s : active) max_npk = std::max(max_npk, std::min(npk[s], kMaxCand));
+
+        for (int rank = 0; rank < (lockstep ? max_npk : 1); ++rank) {
+            // ---- build the wave ------------------------------------------------
+            std::vector<WaveItem> wave;
+            for (int s : active) {
+                if (stopped[s]) continue;
+                const int n = std::min(npk[s], kMaxCand);
+                if (lockstep) { if (rank < n) wave.push_back(WaveItem{s, rank}); }
+                else for (int j = 0; j < n; ++j) wave.push_back(WaveItem{s, j});
+            }
+            const int nw = (int)wave.size();
+            if (nw == 0) { if (lockstep) continue; else break; }
+
+            // ---- GPU: fine sync (mode 0, mode 1) and first soft-symbol attempt ---
+            FineState* h_items = static_cast<FineState*>(c.h_items.need((size_t)nw * sizeof(FineState)));
+            for (int i = 0; i < nw; ++i) {
+                const DevCand& cd = cand[(size_t)wave[i].seg * kMaxCand + wave[i].cand];
+                FineState f{};
+                f.seg = wave[i].seg; f.freq = cd.freq; f.drift = cd.drift; f.shift = cd.shift; f.sync = cd.sync;
+                f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
+                h_items[i] = f;
+            }
+            FineState* d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
+            const int nh_max = std::max(nlag0, kMaxLags);
+            float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
+            unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
+            float* d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
+            const float* wi = c.iqI.as<float>();
+            const float* wq = c.iqQ.as<float>();
+            float* h_sync = static_cast<float*>(c.h_sync.need((size_t)nw * kMaxLags * 4));
+            float* h_rms = static_cast<float*>(c.h_rms.need((size_t)nw * kMaxLags * 4));
+            unsigned char* h_sym = static_cast<unsigned char*>(c.h_sym.need((size_t)nw * kMaxLags * kNSymD));
+            {
+                Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
+                upload(d_items, h_items, (size_t)nw * sizeof(FineState), c.stream);
+                launch_demod(wi, wq, samples, d_items, nw, 0, nlag0, lagstep, 0, 0.0f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
+                launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
+                launch_demod(wi, wq, samples, d_items, nw, 1, 5, lagstep, -2, 0.1f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
+                launch_pick_freq(d_items, nw, d_sync, 5, -2, 0.1f, c.stream);
+                launch_demod(wi, wq, samples, d_items, nw, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), minsync1, d_sync, d_sym, d_rms, c.tab, c.stream);
+                HIP_OK(hipMemcpyAsync(h_items, d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
+                HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
+                HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
+                HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)nw * kNSymD, hipMemcpyDeviceToHost, c.stream));
+                t.stop();
+            }
+
+            // ---- host: first rung of the jitter ladder ----------------------------
+            const auto t_f0 = std::chrono::steady_clock::now();
+            c.pool->run(nw, [&](int i) {
+                WaveItem& w = wave[i];
+                w.fine = h_items[i];
+                w.worth = w.fine.sync > minsync1;
+                w.decoded = false;
+                w.jitter = 0;
+                if (!w.worth) return;
+                if (h_sync[i] > minsync2 && h_rms[i] > minrms) {
+                    unsigned char sym[kNSymD];
+                    memcpy(sym, h_sym + (size_t)i * kNSymD, kNSymD);
+                    deinterleave162(sym);
+                    unsigned metric, maxnp;
+                    memset(w.decdata, 0, sizeof w.decdata);
+                    const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
+                    w.decoded = (nd == 0);
+                }
+            });
+            c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
+
+            // ---- remaining rungs, only for candidates that still need them --------
+            std::vector<int> again;
+            if (njit_rest > 0)
+                for (int i = 0; i < nw; ++i)
+                    if (wave[i].worth && !wave[i].decoded) again.push_back(i);
+            if (!again.empty()) {
+                const int na = (int)again.size();
+                FineState* h2 = static_cast<FineState*>(c.h_misc.need((size_t)na * sizeof(FineState)));
+                for (int a = 0; a < na; ++a) h2[a] = wave[again[a]].fine;
+                {
+                    Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
+                    upload(d_items, h2, (size_t)na * sizeof(FineState), c.stream);
+                    launch_demod(wi, wq, samples, d_items, na, 2, njit_rest, lagstep, 0, 0.0f, c.t_jitter.as<int>() + 1, minsync1,
+                                 d_sync, d_sym, d_rms, c.tab, c.stream);
+                    HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * njit_rest * 4, hipMemcpyDeviceToHost, c.stream));
+                    HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * njit_rest * 4, hipMemcpyDeviceToHost, c.stream));
+                    HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * njit_rest * kNSymD, hipMemcpyDeviceToHost, c.stream));
+                    t.stop();
+                }
+                const auto t_f1 = std::chrono::steady_clock::now();
+                // every (candidate, rung) Fano attempt is independent; the ladder keeps the
+                // FIRST success in rung order, so run them all and pick afterwards
+                struct Attempt { int ok; unsigned cycles; unsigned char data[11]; };
+                std::vector<Attempt> att((size_t)na * njit_rest);
+                std::vector<std::atomic<int>> first(na);
+                for (auto& f : first) f.store(njit_rest);
+                c.pool->run(na * njit_rest, [&](int idx) {
+                    const int a = idx / njit_rest, r = idx % njit_rest;
+                    Attempt& at = att[idx];
+                    at.ok = 0;
+                    if (r > first[a].load()) return;           // an earlier rung already decoded
+                    if (!(h_sync[idx] > minsync2 && h_rms[idx] > minrms)) return;
+                    unsigned char sym[kNSymD];
+                    memcpy(sym, h_sym + (size_t)idx * kNSymD, kNSymD);
+                    deinterleave162(sym);
+                    unsigned metric, maxnp;
+                    memset(at.data, 0, sizeof at.data);
+                    if (fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles) == 0) {
+                        at.ok = 1;
+                        int cur = first[a].load();
+                        while (r < cur && !first[a].compare_exchange_weak(cur, r)) {}
+                    }
+                });
+                for (int a = 0; a < na; ++a) {
+                    const int r = first[a].load();
+                    if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
+                        WaveItem& w = wave[again[a]];
+                        w.decoded = true;
+                        w.jitter = c.jitter_ladder[r + 1];
+                        w.cycles = att[(size_t)a * njit_rest + r].cycles;
+                        memcpy(w.decdata, att[(size_t)a * njit_rest + r].data, 11);
+                    }
+                }
+                c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f1).count();
+            }
+
+            // ---- host bookkeeping in candidate order (wsprd.c:768-822) ------------
+            std::vector<SubJob> jobs;
+            for (int i = 0; i < nw; ++i) {
+                WaveItem& w = wave[i];
+                const int s = w.seg;
+                if (stopped[s]) continue;
+                DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
+                cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
+                if (!(w.worth && w.decoded)) continue;
+
+                signed char message[12] = {0};
+                for (int k = 0; k < 11; ++k) message[k] = (signed char)w.decdata[k];
+                char callsign[13] = {0}, call_loc_pow[23] = {0}, call[13] = {0}, loc[7] = {0}, pwr[3] = {0};
+                SegBook& bk = book[s];
+                const int noprint = unpack_message(message, hashtab_of(s), loctab_of(s), call_loc_pow, call, loc, pwr, callsign);
+                bk.dirty.push_back((int)nhash15(callsign, strlen(callsign), 146u));
+                if (opt.subtraction && ipass == 0 && !noprint) {
+                    SubJob jb{};
+                    if (channel_symbols(call_loc_pow, hashtab_of(s), loctab_of(s), jb.sym)) {
+                        jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
+                        jobs.push_back(jb);
+                    } else {
+                        stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
+                        continue;
+                    }
+                }
+                if (!strcmp(loc, "A000AA")) { stopped[s] = 1; continue; }      // wsprd.c:792-793
+                bool dupe = false;
+                for (int u = 0; u < bk.uniques; ++u)
+                    if (!strcmp(callsign, bk.allcalls[u]) && fabs(w.fine.freq - bk.allfreqs[u]) < 3.0) dupe = true;
+                if (dupe || bk.uniques >= 100) continue;
+                snprintf(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], "%s", callsign);
+                bk.allfreqs[bk.uniques] = w.fine.freq;
+                bk.uniques++;
+                if (bk.uniques <= max_results) {
+                    decoder_results* o = out + (size_t)s * max_results + (bk.uniques - 1);
+                    const double dial = (double)opt.freq / 1e6;
+                    o->sync = w.fine.sync;
+                    // candidates[j].snr, wsprd.c:616, recomputed with the host libm from the
+                    // peak value so that the reported figure does not depend on ocml's log10f
+                    o->snr = 10.0 * log10f(cd.peak) - (float)26.3;
+                    o->dt = w.fine.shift * 1.0 / 375.0 - 2.0;
+                    o->freq = dial + (1500.0 + w.fine.freq) / 1e6;
+                    o->drift = w.fine.drift;
+                    o->cycles = (int)w.cycles;
+                    o->jitter = w.jitter;
+                    snprintf(o->message, sizeof o->message, "%s", call_loc_pow);
+                    snprintf(o->call, sizeof o->call, "%s", call);
+                    snprintf(o->loc, sizeof o->loc, "%s", loc);
+                    snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
+                }
+            }
+
+            // ---- GPU: subtract everything that decoded in this wave ------------------
+            if (!jobs.empty()) {
+                const int nj = (int)jobs.size();
+                SubJob* hj = static_cast<SubJob*>(c.h_jobs.need((size_t)nj * sizeof(SubJob)));
+                memcpy(hj, jobs.data(), (size_t)nj * sizeof(SubJob));
+                SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nj * sizeof(SubJob)));
+                float* scratch = static_cast<float*>(c.subscratch.need((size_t)nj * 4 * kSigLen * 4));
+                Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[4]);
+                upload(dj, hj, (size_t)nj * sizeof(SubJob), c.stream);
+                launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nj, scratch, c.tab, c.stream);
+                t.stop();
+            }
+        }
+    }
+
+    // results strongest first (wsprd.c:827; stable like glibc's merge sort)
+    for (int s = 0; s < nseg; ++s) {
+        SegBook& bk = book[s];
+        const int n = std::min(bk.uniques, max_results);
+        decoder_results* o = out + (size_t)s * max_results;
+        std::stable_sort(o, o + n, [](const decoder_results& a, const decoder_results& b) { return a.snr > b.snr; });
+        n_results[s] = n;
+        for (int slot : bk.dirty) {
+            memset(hashtab_of(s) + (size_t)slot * kHashWidth, 0, kHashWidth);
+            memset(loctab_of(s) + (size_t)slot * kLocWidth, 0, kLocWidth);
+        }
+    }
+    c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
+    return 0;
+}
+
+int Context::last_timings(double* ms, int cap) {
+    const int n = std::min(cap, 7);
+    for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
+    return n;
+}
+
+// average kernel durations of the FFT+sync stage, HIP events on the launch stream
+int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
+    const int blocks = 4 * (samples / kFftSize) - 1;
+    float* ps = ps_buffer(nseg);
+    DevCand* cand = static_cast<DevCand*>(d->cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
+    int* npk = static_cast<int*>(d->npk.need((size_t)nseg * 4));
+    std::vector<hipEvent_t> ev(4 * (size_t)iters);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    for (int it = 0; it < iters; ++it) {
+        HIP_OK(hipEventRecord(ev[4 * it + 0], d->stream));
+        launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), nullptr, nseg, samples, ps, d->tab, d->stream);
+        HIP_OK(hipEventRecord(ev[4 * it + 1], d->stream));
+        launch_pick_peaks(ps, nullptr, nseg, blocks, cand, npk, nullptr, nullptr, d->tab, d->stream);
+        HIP_OK(hipEventRecord(ev[4 * it + 2], d->stream));
+        launch_coarse_sync(ps, nullptr, nseg, blocks, cand, npk, 4, d->tab, d->stream);
+        HIP_OK(hipEventRecord(ev[4 * it + 3], d->stream));
+    }
+    HIP_OK(hipStreamSynchronize(d->stream));
+    ms[0] = ms[1] = ms[2] = 0.0;
+    for (int it = 0; it < iters; ++it)
+        for (int k = 0; k < 3; ++k) {
+            float t = 0;
+            HIP_OK(hipEventElapsedTime(&t, ev[4 * it + k], ev[4 * it + k + 1]));
+            ms[k] += t / iters;
+        }
+    for (auto& e : ev) hipEventDestroy(e);
+    return 3;
+}
+
+// ------------------------------------------------------- single-call stages --
+void Context::demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin,
+                           int ifmax, float fstep, int* shift, int lagmin, int lagmax, int lagstep,
+                           float* drift, float* sync, int mode) {
+    Impl& c = *d;
+    const int samples = (int)std::min<long>(np, kMaxSamples);
+    load_host(id, qd, 1, samples, (size_t)samples);
+    FineState f{};
+    f.seg = 0; f.freq = *freq; f.drift = *drift; f.shift = *shift; f.sync = 1e30f;
+    f.freq_coarse = *freq; f.shift_coarse = lagmin + 128;
+    FineState* d_items = static_cast<FineState*>(c.items.need(sizeof(FineState)));
+    upload(d_items, &f, sizeof f, c.stream);
+    const float* wi = c.iqI.as<float>();
+    const float* wq = c.iqQ.as<float>();
+    if (mode == 0) {
+        const int nl = (lagmax - lagmin) / lagstep + 1;
+        float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nl * 4));
+        launch_demod(wi, wq, (int)np, d_items, 1, 0, nl, lagstep, 0, 0.0f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
+        launch_pick_lag(d_items, 1, d_sync, nl, lagstep, c.stream);
+    } else if (mode == 1) {
+        const int nf = ifmax - ifmin + 1;
+        float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nf * 4));
+        launch_demod(wi, wq, (int)np, d_items, 1, 1, nf, lagstep, ifmin, fstep, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
+        launch_pick_freq(d_items, 1, d_sync, nf, ifmin, fstep, c.stream);
+    } else {
+        float* d_sync = static_cast<float*>(c.syncbuf.need(4));
+        unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need(kNSymD));
+        float* d_rms = static_cast<float*>(c.rmsbuf.need(4));
+        launch_demod(wi, wq, (int)np, d_items, 1, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), -INFINITY, d_sync, d_sym, d_rms, c.tab, c.stream);
+        float s2 = 0;
+        HIP_OK(hipMemcpyAsync(&s2, d_sync, 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(symbols, d_sym, kNSymD, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipStreamSynchronize(c.stream));
+        *sync = s2;
+        return;
+    }
+    HIP_OK(hipMemcpyAsync(&f, d_items, sizeof f, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipStreamSynchronize(c.stream));
+    *sync = f.sync; *shift = f.shift; *freq = f.freq;
+}
+
+void Context::subtract_single(float* id, float* qd, long np, float f0, int shift, float drift,
+                              const unsigned char* sym) {
+    Impl& c = *d;
+    const int samples = (int)std::min<long>(np, kMaxSamples);
+    load_host(id, qd, 1, samples, (size_t)samples);
+    SubJob jb{};
+    jb.seg = 0; jb.f0 = f0; jb.shift = shift; jb.drift = drift;
+    memcpy(jb.sym, sym, kNSymD);
+    SubJob* dj = static_cast<SubJob*>(c.jobs.need(sizeof jb));
+    upload(dj, &jb, sizeof jb, c.stream);
+    float* scratch = static_cast<float*>(c.subscratch.need((size_t)4 * kSigLen * 4));
+    launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), (int)np, dj, 1, scratch, c.tab, c.stream);
+    store_host(id, qd, 1, samples, (size_t)samples);
+}
+
+int Context::decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
+                             int* h_nout) {
+    Impl& c = *d;
+    const size_t nblocks = bytes_per_seg / 2 / 6401;
+    if (nblocks == 0) return -1;
+    int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
+    int* d_nv = static_cast<int*>(c.nvalid.need((size_t)nseg * 4));
+    HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, c.stream));
+    HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, c.stream));
+    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream);
+    if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
+    if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+}  // namespace wspr

@@ -1,0 +1,222 @@
+// K2 -- candidate peak picker, K3 -- coarse (frequency, lag, drift) sync search.
+//
+// K2 replaces reference wsprd/wsprd.c:555-631, K3 replaces :646-678.  Both read
+// the power spectrogram written by K1 and are bound by that read (HBM/L2):
+// 578 796 algorithmic bytes per segment per pass.
+//
+// Float evaluation order is the reference's: every sum that feeds a threshold or
+// an argmax is accumulated by ONE lane in the reference's loop order; lanes
+// parallelise over independent sums (bins, or (freq, lag, drift) hypotheses).
+#include "wspr_device.h"
+
+#pragma clang fp contract(off)
+
+namespace wspr {
+namespace {
+
+constexpr double kHalfDf = 375.0 / 256.0 / 2.0;      // (DF / 2.0), wsprd.c:615
+
+// ------------------------------------------------------------------ K2 ------
+// One workgroup per segment.
+__global__ __launch_bounds__(512)
+void pick_peaks_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
+                       DevCand* __restrict__ cand, int* __restrict__ npk_out,
+                       float* __restrict__ noise_out, float* __restrict__ smspec_out,
+                       float min_snr, float floor_snr) {
+    __shared__ float avg[kPsBins];
+    __shared__ float sm[kSmooth];
+    __shared__ float nrm[kSmooth];
+    __shared__ float noise_s;
+    __shared__ int   pk_bin[kMaxCand];
+    __shared__ float pk_snr[kMaxCand];
+    __shared__ int   kept_s;
+
+    const int tid = threadIdx.x;
+    const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
+    const float* __restrict__ P = ps + (size_t)seg * kMaxBlocks * kPsStride;
+
+    // time-averaged spectrum: lane = bin, serial over time (wsprd.c:556-561)
+    if (tid < kPsBins) {
+        float acc = 0.0f;
+        for (int t = 0; t < blocks; ++t) acc += P[(size_t)t * kPsStride + tid];
+        avg[tid] = acc;
+    }
+    if (tid == 0) noise_s = 0.0f;
+    __syncthreads();
+
+    // 7-bin boxcar, bins 51+i-3 .. 51+i+3 (wsprd.c:565-573); column = bin - 48
+    if (tid < kSmooth) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) acc += avg[tid + d];
+        sm[tid] = acc;
+        if (smspec_out) smspec_out[(size_t)seg * kSmooth + tid] = acc;
+    }
+    __syncthreads();
+
+    // 30th percentile = element 122 of the ascending sort (wsprd.c:576-583), by rank counting
+    if (tid < kSmooth) {
+        const float v = sm[tid];
+        int less = 0, leq = 0;
+        for (int j = 0; j < kSmooth; ++j) {
+            const float u = sm[j];
+            less += (u < v);
+            leq  += (u <= v);
+        }
+        if (less <= 122 && 122 < leq) noise_s = v;
+    }
+    __syncthreads();
+    const float noise = noise_s;
+
+    // snr-like normalisation with floor (wsprd.c:590-597)
+    if (tid < kSmooth) {
+        const float q = sm[tid] / noise;
+        float v = (float)((double)q - 1.0);
+        if (v < min_snr) v = floor_snr;
+        nrm[tid] = v;
+    }
+    __syncthreads();
+
+    // strict local maxima, first 200 only, then the +-110 Hz window (wsprd.c:608-629)
+    if (tid == 0) {
+        int found = 0, kept = 0;
+        for (int j = 1; j < kSmooth - 1; ++j) {
+            const float v = nrm[j];
+            if (v > nrm[j - 1] && v > nrm[j + 1] && found < kMaxCand) {
+                ++found;
+                const float f = (float)((double)(j - 205) * kHalfDf);
+                if (f >= -110.0f && f <= 110.0f) {
+                    pk_bin[kept] = j;
+                    pk_snr[kept] = (float)(10.0 * (double)log10f(v) - (double)26.3f);
+                    ++kept;
+                }
+            }
+        }
+        kept_s = kept;
+        npk_out[seg] = kept;
+        if (noise_out) noise_out[seg] = noise;
+    }
+    __syncthreads();
+
+    // stable sort by snr, strongest first (wsprd.c:631; glibc qsort is a merge sort)
+    const int kept = kept_s;
+    if (tid < kept) {
+        const float mine = pk_snr[tid];
+        int rank = 0;
+        for (int j = 0; j < kept; ++j) {
+            const float o = pk_snr[j];
+            rank += (o > mine) || (o == mine && j < tid);
+        }
+        const int j = pk_bin[tid];
+        DevCand cd;
+        cd.freq  = (float)((double)(j - 205) * kHalfDf);
+        cd.snr   = mine;
+        cd.peak  = nrm[j];
+        cd.shift = 0;
+        cd.drift = 0.0f;
+        cd.sync  = 0.0f;
+        cand[(size_t)seg * kMaxCand + rank] = cd;
+    }
+}
+
+// ------------------------------------------------------------------ K3 ------
+// One workgroup per (segment, candidate); lane = one (frequency bin, lag, drift
+// pattern) hypothesis, accumulating its 162-term sums in symbol order.
+//
+// Reference quirks reproduced:
+//  * "/ DF" expands to "/375.0/256.0", so the per-symbol drift offset only ever
+//    lowers the bin by one for (k>81, drift<0) or (k<81, drift>0): three distinct
+//    patterns; with a strict '>' the first drift of each sign wins, i.e. the label
+//    is -maxdrift, 0 or +1.
+//  * a negative time index reads the previous bin's row, 347+index.
+constexpr int kCoarseRows = 11;
+constexpr int kCoarsePitch = 352;
+
+__global__ __launch_bounds__(320)
+void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
+                        DevCand* __restrict__ cand, const int* __restrict__ npk, int maxdrift,
+                        const unsigned char* __restrict__ pr3) {
+    __shared__ float amp[kCoarseRows * kCoarsePitch];
+    __shared__ float res[288];
+    const int tid = threadIdx.x;
+    const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
+    const float* __restrict__ P = ps + (size_t)seg * kMaxBlocks * kPsStride;
+    const int ncand = npk[seg];
+    const int npat = (maxdrift > 0) ? 3 : 1;
+    const int nhyp = 3 * 32 * npat;
+
+    for (int c = blockIdx.y; c < ncand; c += gridDim.y) {
+        DevCand cd = cand[(size_t)seg * kMaxCand + c];
+        const int if0 = (int)((double)cd.freq / kHalfDf + 256.0);
+        const int col0 = if0 - 6 - kPsBin0;            // first staged column
+        __syncthreads();
+        for (int e = tid; e < kCoarseRows * blocks; e += blockDim.x) {
+            const int t = e / kCoarseRows, r = e - t * kCoarseRows;
+            amp[r * kCoarsePitch + t] = sqrtf(P[(size_t)t * kPsStride + col0 + r]);
+        }
+        __syncthreads();
+
+        if (tid < nhyp) {
+            const int fi = tid / (32 * npat);
+            const int rem = tid - fi * 32 * npat;
+            const int k0 = rem / npat - 10;
+            const int pat = (npat == 3) ? rem % 3 : 1;     // 0: drift<0, 1: drift 0, 2: drift>0
+            const int ifr = if0 - 1 + fi;
+            float ss = 0.0f, pw = 0.0f;
+            bool any = false;
+            for (int k = 0; k < kNSymD; ++k) {
+                const int low = (pat == 0 && k > 81) || (pat == 2 && k < 81);
+                const int ifd = ifr - low;
+                int kidx = k0 + 2 * k;
+                if (kidx < blocks) {
+                    int row = ifd - 3 - (if0 - 6);
+                    if (kidx < 0) { row -= 1; kidx += blocks; }   // previous row of the flat array
+                    const float* a = amp + row * kCoarsePitch + kidx;
+                    const float p0 = a[0], p1 = a[2 * kCoarsePitch], p2 = a[4 * kCoarsePitch], p3 = a[6 * kCoarsePitch];
+                    const float m = (p1 + p3) - (p0 + p2);
+                    ss = pr3[k] ? ss + m : ss - m;
+                    pw = pw + p0 + p1 + p2 + p3;
+                    any = true;
+                }
+            }
+            res[tid] = any ? ss / pw : __int_as_float(0x7fc00000);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float best = -1e30f;
+            int arg = -1;
+            for (int h = 0; h < nhyp; ++h)
+                if (res[h] > best) { best = res[h]; arg = h; }
+            if (arg >= 0) {
+                const int fi = arg / (32 * npat);
+                const int rem = arg - fi * 32 * npat;
+                const int k0 = rem / npat - 10;
+                const int pat = (npat == 3) ? rem % 3 : 1;
+                cd.shift = 128 * (k0 + 1);
+                cd.drift = (pat == 0) ? (float)(-maxdrift) : (pat == 2 ? 1.0f : 0.0f);
+                cd.freq  = (float)((double)(if0 - 1 + fi - 256) * kHalfDf);
+                cd.sync  = best;
+                cand[(size_t)seg * kMaxCand + c] = cd;
+            }
+        }
+    }
+}
+}  // namespace
+
+void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks,
+                       DevCand* cand, int* npk, float* noise_out, float* smspec_out,
+                       const DeviceTables& t, hipStream_t st) {
+    if (nseg_active <= 0) return;
+    hipLaunchKernelGGL(pick_peaks_kernel, dim3(nseg_active), dim3(512), 0, st, ps, seg_list, blocks,
+                       cand, npk, noise_out, smspec_out, t.min_snr, t.floor_snr);
+}
+
+void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, int blocks,
+                        DevCand* cand, const int* npk, int maxdrift,
+                        const DeviceTables& t, hipStream_t st) {
+    if (nseg_active <= 0) return;
+    hipLaunchKernelGGL(coarse_sync_kernel, dim3(nseg_active, 8), dim3(320), 0, st, ps, seg_list, blocks,
+                       cand, npk, maxdrift, t.sync);
+}
+
+}  // namespace wspr

@@ -1,0 +1,101 @@
+// Device-side data layout and kernel launchers of the MI355X WSPR decoder.
+//
+// HBM layout (all float32 unless noted), sized for thousands of resident
+// 2-minute segments (one segment = 45 000 complex samples at 375 sps):
+//   iq      I[nseg][kIqStride], Q[nseg][kIqStride]   planar, rows 256-B aligned
+//   ps      [nseg][blocks<=347][kPsStride]           |X|^2, bin-contiguous rows,
+//                                                     column b = fft-shifted bin 48+b
+//   cand    DevCand[nseg][200] + npk[nseg]            peak list, strongest first
+// Everything a kernel needs besides these is a small constant table uploaded once
+// (window, twiddles, sync vector, subtraction low-pass taps).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wspr {
+
+constexpr int kMaxSamples = 45000;
+constexpr int kIqStride   = 45056;      // 176 * 256
+constexpr int kFftSize    = 512;
+constexpr int kHop        = 128;
+constexpr int kMaxBlocks  = 347;        // 4*floor(45000/512) - 1
+constexpr int kPsBin0     = 48;         // first fft-shifted bin kept
+constexpr int kPsBins     = 417;        // bins 48..464 (all that any consumer reads)
+constexpr int kPsStride   = 432;        // floats per (segment, time) row
+constexpr int kSmooth     = 411;        // smoothed-spectrum length
+constexpr int kMaxCand    = 200;
+constexpr int kNSymD      = 162;
+constexpr int kSps        = 256;
+constexpr int kSigLen     = kNSymD * kSps;   // 41 472 samples of signal
+constexpr int kLpfTaps    = 360;
+constexpr int kMaxLags    = 43;
+
+struct DevCand {
+    float freq;     // Hz relative to 1500 Hz
+    float snr;      // dB in 2500 Hz (device log10f)
+    float peak;     // normalised smoothed-spectrum value the snr derives from
+    int   shift;    // samples
+    float drift;    // Hz over the frame
+    float sync;
+};
+
+// One candidate being refined/demodulated (fine sync, soft symbols)
+struct FineState {
+    int   seg;
+    float freq;         // in: coarse freq  -> after mode 1: refined freq
+    float drift;
+    int   shift;        // in: coarse shift -> after mode 0: refined shift
+    float sync;         // sync after the latest mode-0/1 search
+    int   shift_coarse; // kept so that the lag window can be rebuilt
+    float freq_coarse;
+    int   pad;
+};
+
+// One coherent subtraction job
+struct SubJob {
+    int   seg;
+    float f0;
+    int   shift;
+    float drift;
+    unsigned char sym[kNSymD];
+    unsigned char pad[2];
+};
+
+struct DeviceTables {
+    const float*  window;      // [512]  sinf(0.006147931*j)
+    const float2* twiddle;     // [256]  exp(-2*pi*i*k/512), float
+    const unsigned char* sync; // [162]
+    const float*  lpf;         // [360]  normalised sine taps
+    const float*  lpf_part;    // [360]  running sums for the edge correction
+    float min_snr;             // powf(10, -0.8)
+    float floor_snr;           // 0.1 * min_snr
+};
+
+// ---- launchers (all asynchronous on `st`) ----------------------------------
+void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
+                     int samples, float* ps, const DeviceTables& t, hipStream_t st);
+void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks,
+                       DevCand* cand, int* npk, float* noise_out, float* smspec_out,
+                       const DeviceTables& t, hipStream_t st);
+void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, int blocks,
+                        DevCand* cand, const int* npk, int maxdrift,
+                        const DeviceTables& t, hipStream_t st);
+// nhyp hypotheses per item, results in sync_out[item][nhyp]:
+// mode 0: lags shift_coarse-128 + lagstep*h at freq_coarse
+// mode 1: frequencies state.freq + (ifmin+h)*fstep at state.shift
+// mode 2: lags state.shift + jitter[h] at state.freq; also soft symbols and their rms;
+//         skipped (nothing written) for items whose state.sync <= minsync1
+void launch_demod(const float* dI, const float* dQ, int samples, const FineState* items, int nitems,
+                  int mode, int nhyp, int lagstep, int ifmin, float fstep, const int* jitter,
+                  float minsync1, float* sync_out, unsigned char* sym_out, float* rms_out,
+                  const DeviceTables& t, hipStream_t st);
+void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st);
+void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nfreq, int ifmin,
+                      float fstep, hipStream_t st);
+void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
+                     float* scratch /* njobs * 5 * kSigLen floats */, const DeviceTables& t, hipStream_t st);
+void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
+void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
+                     int* n_out, int32_t* scratch, hipStream_t st);
+
+}  // namespace wspr

@@ -1,0 +1,246 @@
+"""GPU parity tests: every HIP stage, called through the C ABI of libwspr_mi355x.so,
+against the CPU oracle on the same inputs.  Bit-exact unless stated."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+pytestmark = pytest.mark.gpu
+
+NS = 45000
+
+
+@pytest.fixture(scope="module")
+def w():
+    import rtlsdr_wsprd_amd as mod
+    assert mod.lib().wspr_device_ready() == 1
+    return mod
+
+
+def symf(msg):
+    ok, s = ol.channel_symbols(msg)
+    assert ok
+    return s
+
+
+@pytest.fixture(scope="module")
+def ref_iq():
+    I, Q, n = ol.read_iq_file(os.path.join(ol.GOLDEN, "refSignalSnr0dB.iq"))
+    return I, Q
+
+
+@pytest.fixture(scope="module")
+def synth_batch():
+    segs = [synth.make_segment(1000 + s, symf, snr_db=-20.0) for s in range(6)]
+    segs.append(synth.make_segment(77, symf, n_signals=4, snr_db=-8.0, snr_span=12.0, t_jitter=0.3))
+    segs.append(synth.make_segment(78, symf, snr_db=-15.0, drift=2.0))
+    I = np.stack([s[0] for s in segs])
+    Q = np.stack([s[1] for s in segs])
+    return I, Q, [s[2] for s in segs]
+
+
+def oracle_ps(I, Q, n=NS):
+    L = ol.lib()
+    blocks = L.orc_blocks_for(n)
+    ps = np.zeros((512, blocks), np.float32)
+    L.orc_fft_bank(ol.ptr(I), ol.ptr(Q), C.c_int(n), ol.ptr(ps))
+    return ps
+
+
+# ------------------------------------------------------------------ K1
+def test_fft_bank_bit_exact_vs_oracle_and_close_to_numpy(w, synth_batch, ref_iq):
+    I = np.stack([ref_iq[0], synth_batch[0][0], synth_batch[0][6]])
+    Q = np.stack([ref_iq[1], synth_batch[1][0], synth_batch[1][6]])
+    blocks = 347
+    out = np.zeros((3, 512, blocks), np.float32)
+    rc = w.lib().wspr_stage_fft_bank(ol.ptr(I), ol.ptr(Q), 3, NS, NS, ol.ptr(out))
+    assert rc == blocks
+    for s in range(3):
+        ps = oracle_ps(I[s], Q[s])
+        assert np.array_equal(out[s, 48:465], ps[48:465])            # same butterflies -> same bits
+        assert not out[s, :48].any() and not out[s, 465:].any()
+    # independent check of the FFT itself (double precision numpy), SURVEY parity gate 1e-5
+    win = np.sin(np.float32(1.0) * 0.006147931 * np.arange(512)).astype(np.float32)
+    t = 100
+    x = (I[0, 128 * t:128 * t + 512].astype(np.float64) + 1j * Q[0, 128 * t:128 * t + 512]) * win
+    p = np.abs(np.fft.fftshift(np.fft.fft(x))) ** 2
+    assert np.allclose(out[0, 48:465, t], p[48:465], rtol=2e-4, atol=1e-4 * p.max())
+
+
+# ------------------------------------------------------------------ K2 + K3
+def _oracle_cands(I, Q, coarse):
+    L = ol.lib()
+    ps = oracle_ps(I, Q)
+    cands = (ol.Cand * 200)()
+    noise = C.c_float()
+    sm = np.zeros(411, np.float32)
+    npk = L.orc_pick_peaks(ol.ptr(ps), C.c_int(347), cands, C.byref(noise), ol.ptr(sm), None)
+    if coarse:
+        L.orc_coarse_sync(ol.ptr(ps), C.c_int(347), cands, C.c_int(npk), C.c_int(4))
+    return npk, cands, noise.value, sm
+
+
+@pytest.mark.parametrize("coarse", [0, 1])
+def test_candidates_match_oracle(w, synth_batch, ref_iq, coarse):
+    I = np.concatenate([ref_iq[0][None], synth_batch[0]])
+    Q = np.concatenate([ref_iq[1][None], synth_batch[1]])
+    nseg = I.shape[0]
+    cands = (w.cand * (200 * nseg))()
+    npk = (C.c_int * nseg)()
+    noise = np.zeros(nseg, np.float32)
+    sm = np.zeros((nseg, 411), np.float32)
+    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, coarse, 4, C.addressof(cands),
+                                       C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
+    assert rc == 0
+    for s in range(nseg):
+        onpk, oc, onoise, osm = _oracle_cands(I[s], Q[s], coarse)
+        assert npk[s] == onpk
+        assert noise[s] == np.float32(onoise)
+        assert np.array_equal(sm[s], osm)
+        for j in range(onpk):
+            g, o = cands[200 * s + j], oc[j]
+            assert (g.freq, g.shift, g.drift, g.sync) == (o.freq, o.shift, o.drift, o.sync), (s, j)
+            assert g.snr == pytest.approx(o.snr, abs=2e-5)          # ocml vs glibc log10f
+
+
+# ------------------------------------------------------------------ K4 / K5
+def _both_demod(w, I, Q, freq, shift, drift, mode, lagmin=0, lagmax=0, lagstep=8, ifmin=0, ifmax=0, fstep=0.0, np_=NS):
+    res = []
+    for which in ("gpu", "cpu"):
+        Ic, Qc = I.copy(), Q.copy()
+        f = C.c_float(freq); sh = C.c_int(shift); dr = C.c_float(drift); sy = C.c_float(0)
+        sym = (C.c_ubyte * 162)()
+        args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(np_), sym, C.addressof(f), ifmin, ifmax, C.c_float(fstep),
+                C.addressof(sh), lagmin, lagmax, lagstep, C.addressof(dr), 50, C.addressof(sy), mode]
+        if which == "gpu":
+            w.lib().sync_and_demodulate(*args)
+        else:
+            ol.lib().orc_sync_demod(*args)
+        res.append((f.value, sh.value, sy.value, bytes(sym)))
+    return res
+
+
+@pytest.mark.parametrize("seg,drift", [(0, 0.0), (3, 0.0), (7, 2.0), (7, -4.0), (6, 1.0)])
+def test_sync_and_demodulate_modes_bit_exact(w, synth_batch, seg, drift):
+    I, Q, truth = synth_batch
+    msg, f0, t0, snr = truth[seg][0]
+    fc = float(np.float32(round(f0 / 0.732421875) * 0.732421875))
+    sc = int(round(t0 * 375 / 128.0)) * 128
+    g, o = _both_demod(w, I[seg], Q[seg], fc, sc, drift, 0, lagmin=sc - 128, lagmax=sc + 128, lagstep=8)
+    assert g[:3] == o[:3]
+    shift = o[1]
+    g, o = _both_demod(w, I[seg], Q[seg], fc, shift, drift, 1, ifmin=-2, ifmax=2, fstep=0.1)
+    assert g[:3] == o[:3]
+    fbest = o[0]
+    for jig in (0, -3, 3, 63, -63):
+        g, o = _both_demod(w, I[seg], Q[seg], fbest, shift + jig, drift, 2)
+        assert g[2] == o[2] and g[3] == o[3]
+
+
+def test_sync_and_demodulate_edges(w, synth_batch):
+    """Signal window hanging off both ends of the buffer (partial decode) and short np."""
+    I, Q, _ = synth_batch
+    for shift in (-1400, -300, 3700, 4100):
+        g, o = _both_demod(w, I[0], Q[0], 10.0, shift, 0.0, 2)
+        assert g[2:] == o[2:]
+        g, o = _both_demod(w, I[0], Q[0], -37.5, shift, 1.0, 0, lagmin=shift - 128, lagmax=shift + 128, lagstep=16)
+        assert g[:3] == o[:3]
+    g, o = _both_demod(w, I[0], Q[0], 10.0, 700, 0.0, 2, np_=44000)
+    assert g[2:] == o[2:]
+
+
+# ------------------------------------------------------------------ K7
+@pytest.mark.parametrize("seg,drift,shift_off", [(0, 0.0, 0), (6, 0.0, 0), (7, 2.0, 0), (1, 0.0, -2500), (2, -1.0, 3900)])
+def test_subtract_signal2_bit_exact(w, synth_batch, seg, drift, shift_off):
+    I, Q, truth = synth_batch
+    msg, f0, t0, snr = truth[seg][0]
+    sym = symf(msg)
+    shift = int(round(t0 * 375)) + shift_off
+    outs = []
+    for which in ("gpu", "cpu"):
+        Ic, Qc = I[seg].copy(), Q[seg].copy()
+        args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(NS), C.c_float(f0), C.c_int(shift), C.c_float(drift), ol.ptr(sym)]
+        (w.lib().subtract_signal2 if which == "gpu" else ol.lib().orc_subtract)(*args)
+        outs.append((Ic, Qc))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert not np.array_equal(outs[0][0], I[seg])
+
+
+# ------------------------------------------------------------------ whole path
+def _spot_tuple(s):
+    return (s.message, s.call, s.loc, s.pwr, s.cycles, s.jitter, s.drift, s.sync, s.dt, s.freq)
+
+
+def test_reference_file_spot_line(w, ref_iq):
+    spots, ri, rq = w.wspr_decode(ref_iq[0], ref_iq[1], NS, w.default_options())
+    assert len(spots) == 1
+    assert ol.spot_line(spots[0]) == "Spot :  -0.07   0.01 144.490550  0    K1JT   FN20 20"   # REPORT.md:202
+    ref, oi, oq = ol.decode(ref_iq[0], ref_iq[1], NS)
+    assert _spot_tuple(spots[0]) == _spot_tuple(ref[0])
+    assert abs(spots[0].snr - ref[0].snr) < 1e-4
+    assert np.array_equal(ri, oi) and np.array_equal(rq, oq)        # residual after subtraction
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(quickmode=1), dict(subtraction=0), dict(npasses=1), dict(npasses=3)])
+def test_batch_decode_equals_oracle(w, synth_batch, opts):
+    I, Q, truth = synth_batch
+    got = w.wspr_decode_batch(I, Q, w.default_options(**opts), max_results=16)
+    for s in range(I.shape[0]):
+        ref, _, _ = ol.decode(I[s], Q[s], NS, ol.default_options(**opts))
+        assert [_spot_tuple(x) for x in got[s]] == [_spot_tuple(x) for x in ref], s
+        for a, b in zip(got[s], ref):
+            assert abs(a.snr - b.snr) < 1e-4
+    if not opts:
+        for s in range(6):      # the -20 dB single-signal segments all decode
+            assert [x.message.decode() for x in got[s]] == [synth.expected_text(truth[s][0][0])]
+
+
+def test_empty_and_degenerate_inputs(w):
+    z = np.zeros((2, NS), np.float32)
+    assert w.wspr_decode_batch(z, z) == [[], []]
+    rng = np.random.default_rng(5)
+    n = rng.normal(0, 0.1, (2, NS)).astype(np.float32)
+    got = w.wspr_decode_batch(n, n[::-1].copy())
+    for s in range(2):
+        ref, _, _ = ol.decode(n[s], n[::-1][s], NS)
+        assert [_spot_tuple(x) for x in got[s]] == [_spot_tuple(x) for x in ref]
+    # short record (ragged input): 40000 samples
+    I, Q, _ = synth.make_segment(4242, symf, snr_db=-12.0)
+    spots, _, _ = w.wspr_decode(I[:40000], Q[:40000], 40000)
+    ref, _, _ = ol.decode(np.concatenate([I[:40000], np.zeros(5000, np.float32)]),
+                          np.concatenate([Q[:40000], np.zeros(5000, np.float32)]), 40000)
+    assert [_spot_tuple(x) for x in spots] == [_spot_tuple(x) for x in ref]
+
+
+# ------------------------------------------------------------------ K0
+def test_decimator_bit_exact_vs_oracle(w):
+    rng = np.random.default_rng(11)
+    nsamp = 6401 * 300 + 1000
+    n = np.arange(nsamp)
+    ph = 2 * np.pi * (-600000.0 + 40.0) / 2.4e6 * n
+    sig = 6.0 * np.exp(1j * ph)
+    raw = np.empty(2 * nsamp, np.uint8)
+    raw[0::2] = np.clip(np.round(127.5 + sig.real + rng.normal(0, 10, nsamp)), 0, 255).astype(np.uint8)
+    raw[1::2] = np.clip(np.round(127.5 + sig.imag + rng.normal(0, 10, nsamp)), 0, 255).astype(np.uint8)
+    raw[:64] = 0            # int8 -128 negation case
+    raw[64:128] = 255
+    nbytes = (raw.size // 8) * 8
+    L = ol.lib()
+    st = L.orc_decim_new()
+    oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+    fill = L.orc_decim_feed(C.c_void_p(st), ol.ptr(raw), nbytes, ol.ptr(oi), ol.ptr(oq), 0, NS)
+    L.orc_decim_free(C.c_void_p(st))
+    gi = np.zeros(NS, np.float32); gq = np.zeros(NS, np.float32)
+    nout = C.c_uint32()
+    assert w.lib().wspr_decimate_u8(ol.ptr(raw), nbytes, ol.ptr(gi), ol.ptr(gq), C.byref(nout), 0) == 0
+    assert nout.value == fill == 300
+    assert np.array_equal(gi[:fill], oi[:fill]) and np.array_equal(gq[:fill], oq[:fill])
+    assert np.abs(gi[40:fill]).max() > 1e6       # in-band tone came through the CIC
+    # with normalisation
+    assert w.lib().wspr_decimate_u8(ol.ptr(raw), nbytes, ol.ptr(gi), ol.ptr(gq), C.byref(nout), 1) == 0
+    L.orc_normalise(ol.ptr(oi), ol.ptr(oq), C.c_int(fill), C.c_int(NS))
+    assert np.array_equal(gi, oi) and np.array_equal(gq, oq)
