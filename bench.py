@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- 2-minute WSPR segments decoded per second on MI355X.
+
+Workload (BASELINE.json configs[1]): 1 024 synthetic "wsprsim" segments per GPU, one
+type-1 signal each at SNR -20 dB (2500 Hz reference bandwidth), 45 000 complex f32
+samples per segment at 375 sps, resident in HBM when the timed region starts.
+A step = one full decode of the batch: FFT bank, peak pick, coarse sync, fine sync,
+soft demodulation (HIP kernels), host Fano decode, coherent subtraction (HIP), second
+pass, spot records on the host.  With --gpus N every rank decodes its own 1 024
+segments (weak scaling) and the spot records are gathered on rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import rtlsdr_wsprd_amd as w            # noqa: E402
+from rtlsdr_wsprd_amd import dist as wd  # noqa: E402  (package submodule via the shim's __path__)
+
+NS = 45000
+K1_BYTES = 360000 + 4 * 417 * 347            # IQ read once + ps rows 48..464 written
+K23_BYTES = 4 * 417 * 347 + 4000             # ps read once + candidates
+STAGE_BYTES = K1_BYTES + K23_BYTES           # 1 517 592 B per segment per pass
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch_gpu(nseg, seed, snr_db, dev):
+    """Config-2 segments generated on the GPU (tests/synth.py is the numpy twin)."""
+    import synth
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    msgs = [synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(nseg)]
+    sym = np.stack([w.get_wspr_channel_symbols(m)[1] for m in msgs]).astype(np.float64)
+    f0 = rng.uniform(-100.0, 100.0, nseg)
+    t0 = 2.0 + rng.uniform(-1.0, 1.0, nseg)
+    amp = 10.0 ** (snr_db / 20.0)
+    df, dt = 375.0 / 256.0, 1.0 / 375.0
+    dphi = 2.0 * np.pi * dt * (f0[:, None] + (sym - 1.5) * df)                  # [nseg,162]
+    dphi_t = torch.from_numpy(dphi).to(dev).repeat_interleave(256, dim=1)      # [nseg,41472]
+    phi = torch.cumsum(dphi_t, dim=1) - dphi_t
+    sigma = float(np.sqrt((375.0 / 2500.0) / 2.0))
+    I = torch.randn(nseg, NS, device=dev, generator=g, dtype=torch.float32) * sigma
+    Q = torch.randn(nseg, NS, device=dev, generator=g, dtype=torch.float32) * sigma
+    start = torch.from_numpy(np.round(t0 / dt).astype(np.int64)).to(dev)
+    idx = start[:, None] + torch.arange(162 * 256, device=dev)[None, :]
+    ok = (idx >= 0) & (idx < NS)
+    idx = idx.clamp(0, NS - 1)
+    I.scatter_add_(1, idx, (amp * torch.cos(phi)).float() * ok)
+    Q.scatter_add_(1, idx, (amp * torch.sin(phi)).float() * ok)
+    peak = torch.maximum(I.abs().amax(dim=1), Q.abs().amax(dim=1)).clamp_min(1e-24)
+    scale = (0.5 / peak.double()).float()[:, None]
+    return (I * scale).contiguous(), (Q * scale).contiguous(), [synth.expected_text(m) for m in msgs]
+
+
+def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
+    """Oracle (CPU restatement, oracle/liboracle.so) on a bounded sample of the SAME segments."""
+    import oracle_lib as ol
+    from concurrent.futures import ThreadPoolExecutor
+    ol.lib()
+    cores = os.cpu_count() or 1
+    t = time.perf_counter()
+    ol.decode(I_host[0], Q_host[0], NS)
+    one = time.perf_counter() - t                       # single-core seconds per segment
+    n = int(min(len(I_host), max(cores, budget_s * cores / max(one, 1e-3) * 0.5)))
+    n = max(1, min(n, len(I_host)))
+
+    def run(s):
+        spots, _, _ = ol.decode(I_host[s], Q_host[s], NS)
+        return [x.message.decode() for x in spots]
+
+    t = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:               # ctypes releases the GIL
+        res = list(ex.map(run, range(n)))
+    wall = time.perf_counter() - t
+    return {"value": n / wall, "unit": "segments/s", "cores": cores, "kind": "port",
+            "sample": "%d of the benchmarked segments, oracle/liboracle.so (gcc -O3, scalar C), %d threads; "
+                      "single core %.1f segments/s" % (n, cores, 1.0 / one)}, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--segments", type=int, default=1024, help="segments per GPU")
+    ap.add_argument("--snr", type=float, default=-20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    nseg = args.segments
+    assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
+    I, Q, expected = synth_batch_gpu(nseg, 1234 + rank, args.snr, dev)
+    torch.cuda.synchronize()
+
+    opt = w.default_options()
+    if use_dist:
+        opt = wd.broadcast_options(opt, src=0)          # fan-out of the (tiny) job description
+    dec = w.BatchDecoder(nseg, max_results=16, options=opt)
+    rec = C.sizeof(w.decoder_results)
+
+    def step():
+        dec.decode(I, Q)
+        if use_dist:
+            return wd.gather_spots(wd.pack_spots(dec.out, dec.nres, nseg, dec.max_results, rec), dst=0)
+        return None
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(args.steps):
+        gathered = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # correctness of what was timed: every segment's message must be the transmitted one
+    got = [[s.message.decode() for s in dec.spots(i)] for i in range(nseg)]
+    n_ok = sum(1 for i in range(nseg) if expected[i] in got[i])
+    n_false = sum(len([m for m in got[i] if m != expected[i]]) for i in range(nseg))
+    timings = w.last_timings()
+
+    if rank == 0:
+        total_spots = int(wd.unpack_counts(gathered).sum()) if gathered is not None else dec.total_spots()
+        # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
+        ms = (C.c_double * 3)()
+        w.lib().wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20, C.addressof(ms))
+        k1, k2, k3 = ms[0], ms[1], ms[2]
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_k1_pmc_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": "fft_bank_kernel (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic, "avg_launch_ms": k1, "bytes_per_launch": K1_BYTES * nseg,
+                "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
+                                   "bytes_per_launch": STAGE_BYTES * nseg,
+                                   "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
+                                   "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cnt = min(nseg, 512)
+            Ih, Qh = I[:cnt].cpu().numpy(), Q[:cnt].cpu().numpy()
+            cpu, cpu_msgs = cpu_baseline(Ih, Qh, expected[:cnt])
+            same = sum(1 for i in range(len(cpu_msgs)) if cpu_msgs[i] == got[i])
+            cpu["gpu_equals_cpu_spots"] = "%d/%d segments" % (same, len(cpu_msgs))
+        out = {
+            "metric": "2-minute WSPR segments decoded per second", "value": world * nseg * args.steps / elapsed,
+            "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB, "
+                                   "45000 complex f32 samples @ 375 sps, resident in HBM; reference defaults "
+                                   "(npasses 2, subtraction on, quickmode off)" % (nseg, args.snr),
+                       "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0"},
+            "decoded_ok": "%d/%d" % (n_ok, nseg), "false_decodes": n_false, "spots_total": total_spots,
+            "stage_ms_last_step": timings, "host_threads": os.cpu_count(),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
