@@ -1,0 +1,80 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/wspr_mi355x.h
+declares; struct layouts match the reference's; no product file touches oracle/."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import rtlsdr_wsprd_amd as w
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "wspr_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    funcs = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src))
+    funcs.discard("defined")
+    data = set(re.findall(r"extern\s+[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\]\s*;", src))
+    return funcs, data
+
+
+def test_library_exports_every_declared_symbol():
+    L = w.lib()
+    funcs, data = declared_symbols()
+    assert {"wspr_decode", "wspr_decode_batch", "wspr_decode_batch_device", "get_wspr_channel_symbols",
+            "sync_and_demodulate", "subtract_signal2", "fano", "unpk_", "nhash", "wspr_decimate_u8"} <= funcs
+    missing = [f for f in sorted(funcs | data) if not hasattr(L, f)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_reference():
+    assert C.sizeof(w.decoder_options) == 40 and C.alignment(w.decoder_options) == 4
+    assert [getattr(w.decoder_options, f).offset for f in
+            ("freq", "rcall", "rloc", "quickmode", "usehashtable", "npasses", "subtraction")] == [0, 4, 17, 24, 28, 32, 36]
+    assert C.sizeof(w.decoder_results) == 80 and C.alignment(w.decoder_results) == 8
+    assert [getattr(w.decoder_results, f).offset for f in
+            ("freq", "sync", "snr", "dt", "drift", "jitter", "message", "call", "loc", "pwr", "cycles")] == \
+           [0, 8, 12, 16, 20, 24, 28, 51, 64, 71, 76]
+    assert C.sizeof(w.cand) == 20
+
+
+def test_c_header_compiles_and_agrees_on_sizes(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "wspr_mi355x.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(struct decoder_options),'
+                   'sizeof(struct decoder_results), sizeof(struct cand),'
+                   'offsetof(struct decoder_results, message), offsetof(struct decoder_results, cycles));return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=gnu17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.split() == ["40", "80", "20", "28", "76"]
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    """No CPU fallback: on a box without a HIP device the decode returns an error, not spots."""
+    import numpy as np
+    L = w.lib()
+    if L.wspr_device_ready() == 1:
+        pytest.skip("a GPU is present")
+    z = np.zeros(45000, np.float32)
+    with pytest.raises(RuntimeError):
+        w.wspr_decode(z, z)
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "rtlsdr-wsprd_amd")
+    bad = []
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h", ".py", ".sh")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if f.endswith((".hip", ".cpp", ".h")):      # code only: comments may cite the checker
+                    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+                    txt = re.sub(r"//[^\n]*", "", txt)
+                if re.search(r"liboracle|orc_|oracle/|oracle_lib", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", w.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out

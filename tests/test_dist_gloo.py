@@ -1,0 +1,82 @@
+"""N>1 path on CPU: world_size-2 gloo run of the fan-out / gather helpers bench.py uses.
+Each rank decodes its shard of a small synthetic set with the CPU oracle (the checker; no GPU
+here) and packs spot records exactly as the GPU path does; rank 0 gathers and compares with the
+single-process answer."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NSEG, K = 6, 4
+
+
+def _segments():
+    import oracle_lib as ol
+    import synth
+    symf = lambda m: ol.channel_symbols(m)[1]
+    return [synth.make_segment(500 + s, symf, snr_db=-14.0) for s in range(NSEG)]
+
+
+def _decode_shard(lo, hi, segs, opt):
+    import oracle_lib as ol
+    import rtlsdr_wsprd_amd as w
+    n = hi - lo
+    out = (w.decoder_results * (n * K))()
+    cnt = (C.c_int * n)()
+    o = ol.Options.from_buffer_copy(bytes(opt))
+    for i, s in enumerate(range(lo, hi)):
+        spots, _, _ = ol.decode(segs[s][0], segs[s][1], 45000, o)
+        cnt[i] = min(len(spots), K)
+        for k in range(cnt[i]):
+            C.memmove(C.addressof(out) + (i * K + k) * 80, C.addressof(spots[k]), 80)
+    return out, cnt, n
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rtlsdr_wsprd_amd as w
+    from rtlsdr_wsprd_amd import dist as wd
+    segs = _segments()
+    opt = w.default_options(npasses=2 if rank == 0 else 1)     # only rank 0 holds the real options
+    opt = wd.broadcast_options(opt, src=0)
+    assert opt.npasses == 2 and opt.subtraction == 1 and opt.freq == 144489000
+    lo, hi = wd.shard_range(NSEG, rank, world)
+    out, cnt, n = _decode_shard(lo, hi, segs, opt)
+    g = wd.gather_spots(wd.pack_spots(out, cnt, n, K, 80), dst=0)
+    if rank == 0:
+        q.put((wd.unpack_counts(g).tolist(), wd.unpack_messages(g, K, 80)))
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gather_equals_single_process():
+    sys.path.insert(0, ROOT)
+    import rtlsdr_wsprd_amd as w
+    from rtlsdr_wsprd_amd import dist as wd
+    assert [wd.shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    counts, msgs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    segs = _segments()
+    out, cnt, n = _decode_shard(0, NSEG, segs, w.default_options())
+    single = [[bytes(out[i * K + k].message).split(b"\0")[0].decode() for k in range(cnt[i])] for i in range(NSEG)]
+    flat = [m for r in msgs for m in r]
+    assert flat == single
+    assert sum(map(sum, counts)) == sum(cnt) and sum(cnt) >= NSEG - 1
