@@ -138,8 +138,8 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch;
-    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc;
+        nvalid, decscratch, tabs, pw, lists;
+    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;
     int jitter_ladder[kMaxLags];
     // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
@@ -307,6 +307,21 @@ struct Timer {
 
 }  // namespace
 
+// Assigns each item its slot in the phasor-table buffer (1 table without drift, 162 with) and
+// splits the items into the two launch lists of the tiled demodulator.  Returns the table count.
+static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, int* n_own) {
+    size_t next = 0;
+    int ns = 0, no = 0;
+    for (int i = 0; i < n; ++i) {
+        items[i].pad = (int)next;
+        if (items[i].drift != 0.0f) { next += kNSymD; lists[n + no++] = i; }
+        else                        { next += 1;      lists[ns++] = i; }
+    }
+    *n_shared = ns;
+    *n_own = no;
+    return next;
+}
+
 int Context::decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
                              int max_results, int* n_results) {
     Impl& c = *d;
@@ -399,6 +414,12 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 h_items[i] = f;
             }
             FineState* d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
+            int* h_lists = static_cast<int*>(c.h_lists.need((size_t)nw * 2 * 4));
+            int n_shared = 0, n_own = 0;
+            const size_t ntabs = plan_tables(h_items, nw, h_lists, &n_shared, &n_own);
+            int* d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
+            float* d_tabs = static_cast<float*>(c.tabs.need(ntabs * 2048 * 4));
+            float* d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
             const int nh_max = std::max(nlag0, kMaxLags);
             float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
             unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
@@ -411,7 +432,11 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
             {
                 Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
                 upload(d_items, h_items, (size_t)nw * sizeof(FineState), c.stream);
-                launch_demod(wi, wq, samples, d_items, nw, 0, nlag0, lagstep, 0, 0.0f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
+                upload(d_lists, h_lists, (size_t)nw * 2 * 4, c.stream);
+                // mode 0: lag scan (tiled), mode 1: 5 frequencies, mode 2: first rung of the ladder
+                launch_phasor_tables(d_items, nw, 0, d_tabs, c.stream);
+                launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, nlag0, lagstep,
+                                   0.0f, d_tabs, d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
                 launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
                 launch_demod(wi, wq, samples, d_items, nw, 1, 5, lagstep, -2, 0.1f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
                 launch_pick_freq(d_items, nw, d_sync, 5, -2, 0.1f, c.stream);
@@ -453,14 +478,20 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 const int na = (int)again.size();
                 FineState* h2 = static_cast<FineState*>(c.h_misc.need((size_t)na * sizeof(FineState)));
                 for (int a = 0; a < na; ++a) h2[a] = wave[again[a]].fine;
+                const size_t ntabs2 = plan_tables(h2, na, h_lists, &n_shared, &n_own);
+                d_tabs = static_cast<float*>(c.tabs.need(ntabs2 * 2048 * 4));
                 {
+                    // all 43 lags shift-63 .. shift+63 in steps of 3 (rung r of the ladder = lag index
+                    // (jitter+63)/3; index 21 repeats rung 0 and is ignored)
                     Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
                     upload(d_items, h2, (size_t)na * sizeof(FineState), c.stream);
-                    launch_demod(wi, wq, samples, d_items, na, 2, njit_rest, lagstep, 0, 0.0f, c.t_jitter.as<int>() + 1, minsync1,
-                                 d_sync, d_sym, d_rms, c.tab, c.stream);
-                    HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * njit_rest * 4, hipMemcpyDeviceToHost, c.stream));
-                    HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * njit_rest * 4, hipMemcpyDeviceToHost, c.stream));
-                    HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * njit_rest * kNSymD, hipMemcpyDeviceToHost, c.stream));
+                    upload(d_lists, h_lists, (size_t)na * 2 * 4, c.stream);
+                    launch_phasor_tables(d_items, na, 2, d_tabs, c.stream);
+                    launch_demod_tiled(wi, wq, samples, d_items, na, d_lists, n_shared, d_lists + na, n_own, 2, kMaxLags, 3,
+                                       minsync1, d_tabs, d_pw, d_sync, d_sym, d_rms, c.tab, c.stream);
+                    HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
+                    HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
+                    HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * kMaxLags * kNSymD, hipMemcpyDeviceToHost, c.stream));
                     t.stop();
                 }
                 const auto t_f1 = std::chrono::steady_clock::now();
@@ -475,9 +506,10 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     Attempt& at = att[idx];
                     at.ok = 0;
                     if (r > first[a].load()) return;           // an earlier rung already decoded
-                    if (!(h_sync[idx] > minsync2 && h_rms[idx] > minrms)) return;
+                    const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
+                    if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
                     unsigned char sym[kNSymD];
-                    memcpy(sym, h_sym + (size_t)idx * kNSymD, kNSymD);
+                    memcpy(sym, h_sym + g * kNSymD, kNSymD);
                     deinterleave162(sym);
                     unsigned metric, maxnp;
                     memset(at.data, 0, sizeof at.data);

@@ -37,8 +37,17 @@ void pick_peaks_kernel(const float* __restrict__ ps, const int* __restrict__ seg
 
     // time-averaged spectrum: lane = bin, serial over time (wsprd.c:556-561)
     if (tid < kPsBins) {
+        // the adds are a serial chain (reference order); batch the loads ahead of them
         float acc = 0.0f;
-        for (int t = 0; t < blocks; ++t) acc += P[(size_t)t * kPsStride + tid];
+        int t = 0;
+        for (; t + 16 <= blocks; t += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = P[(size_t)(t + u) * kPsStride + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; t < blocks; ++t) acc += P[(size_t)t * kPsStride + tid];
         avg[tid] = acc;
     }
     if (tid == 0) noise_s = 0.0f;

@@ -151,6 +151,154 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
     }
 }
 
+// =============================================================================
+// Tiled variant for the two wide searches (mode 0: 33/17 lags; ladder rungs: 43 lags).
+//
+// The per-(candidate, symbol) phasor tables do not depend on the lag, and adjacent
+// lags read overlapping samples, so:
+//   phasor_table_kernel  builds each distinct table once (4 tones x 256 steps of the
+//                        reference's float recurrence) -> HBM, 8 KB per table;
+//   demod_tile_kernel    one workgroup per (candidate, 6 consecutive symbols): stages
+//                        the tables and the 6*256 + span samples it needs in LDS (samples
+//                        transposed by the lag step so that the lanes of a symbol read
+//                        consecutive LDS words), then lane = (symbol, lag) runs the same
+//                        256-step matched-filter sums as demod_kernel, in the same order;
+//   demod_metric_kernel  one lane per (candidate, lag) folds the 162 symbols in order.
+// Same arithmetic per accumulator as demod_kernel => identical bits; ~8x less time
+// because loads are coalesced/LDS-served and tables are not recomputed per lag.
+constexpr int kTileSyms = 6;
+
+__global__ __launch_bounds__(64)
+void phasor_table_kernel(const FineState* __restrict__ items, int mode, float* __restrict__ tabs) {
+    const int item = blockIdx.y;
+    const FineState st = items[item];
+    const int lane = threadIdx.x;
+    const int sym = blockIdx.x * 16 + (lane >> 2), tone = lane & 3;
+    const bool drifting = st.drift != 0.0f;
+    if (sym >= kNSymD || (!drifting && sym != 0)) return;
+    const float f0 = (mode == 0) ? st.freq_coarse : st.freq;
+    const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)((float)sym - 81.0f) / (double)81.0f);
+    const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
+    const float dphi = (float)(kTwoPiDt * ((double)fp + off));
+    const float cd = glibc_cosf(dphi), sd = glibc_sinf(dphi);
+    float* __restrict__ t = tabs + ((size_t)st.pad + (drifting ? sym : 0)) * 2048;   // [256][8]
+    float c = 1.0f, s = 0.0f;
+    for (int j = 0; j < kSps; ++j) {
+        if (j > 0) {
+            const float a = c * cd, b = s * sd, e = c * sd, d = s * cd;
+            c = a - b;
+            s = e + d;
+        }
+        t[8 * j + tone] = c;
+        t[8 * j + 4 + tone] = s;
+    }
+}
+
+template <int STEP, bool SHARED>
+__global__ __launch_bounds__(320)
+void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                       const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
+                       int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int item = item_list[blockIdx.y];
+    const FineState st = items[item];
+    if (mode == 2 && !(st.sync > minsync1)) return;
+    const int i0 = blockIdx.x * kTileSyms, tid = threadIdx.x;
+    const int lag0 = (mode == 0) ? st.shift_coarse - 128 : st.shift - 63;
+    constexpr int ntab = SHARED ? 1 : kTileSyms;
+    float4* tab = reinterpret_cast<float4*>(smem);
+    float2* tile = reinterpret_cast<float2*>(smem + ntab * 8192);
+    const int span = kSps * kTileSyms + STEP * (nlag - 1);
+    const int pitch = (span + STEP - 1) / STEP + 1;
+
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)st.pad + (SHARED ? 0 : i0)) * 512;
+    for (int e = tid; e < ntab * 512; e += blockDim.x) tab[e] = gt[e];
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int kbase = lag0 + kSps * i0;
+    for (int e = tid; e < span; e += blockDim.x) {
+        const int k = kbase + e;
+        const bool ok = (k > 0) && (k < np);            // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
+        tile[(e % STEP) * pitch + e / STEP] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+
+    const int il = tid / nlag, m = tid - il * nlag;
+    if (il >= kTileSyms) return;
+    const float4* __restrict__ tb = tab + (SHARED ? 0 : il * 512);
+    float ai[4] = {0.0f, 0.0f, 0.0f, 0.0f}, aq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int e0 = STEP * m + kSps * il;
+#pragma unroll 8
+    for (int j = 0; j < kSps; ++j) {
+        const int e = e0 + j;
+        const float2 d = tile[(e % STEP) * pitch + e / STEP];
+        const float4 c4 = tb[2 * j], s4 = tb[2 * j + 1];
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float m1 = d.x * c[t], m2 = d.y * s[t];
+            const float m3 = d.x * s[t], m4 = d.y * c[t];
+            ai[t] = (ai[t] + m1) + m2;
+            aq[t] = (aq[t] - m3) + m4;
+        }
+    }
+    float p[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float e1 = ai[t] * ai[t], e2 = aq[t] * aq[t];
+        p[t] = sqrtf(e1 + e2);
+    }
+    pw_out[((size_t)item * nlag + m) * kNSymD + i0 + il] = make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// folds the 162 per-symbol tone amplitudes of one (candidate, lag) in symbol order
+__global__ __launch_bounds__(64)
+void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restrict__ items, int nitems,
+                         int mode, int nlag, float minsync1, float* __restrict__ sync_out,
+                         unsigned char* __restrict__ sym_out, float* __restrict__ rms_out,
+                         const unsigned char* __restrict__ pr3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nitems * nlag) return;
+    const int item = idx / nlag;
+    if (mode == 2 && !(items[item].sync > minsync1)) return;
+    const float4* __restrict__ P = pw + (size_t)idx * kNSymD;
+    float ss = 0.0f, totp = 0.0f;
+    for (int k = 0; k < kNSymD; ++k) {
+        const float4 p = P[k];
+        totp = totp + p.x + p.y + p.z + p.w;
+        const float cmet = (p.y + p.w) - (p.x + p.z);
+        ss = pr3[k] ? ss + cmet : ss - cmet;
+    }
+    ss = ss / totp;
+    if (mode != 2) { sync_out[idx] = ss; return; }
+    sync_out[idx] = (ss > -1e30f) ? ss : -1e30f;
+    float fsum = 0.0f, f2sum = 0.0f;
+    for (int k = 0; k < kNSymD; ++k) {
+        const float4 p = P[k];
+        const float f = pr3[k] ? p.w - p.y : p.z - p.x;
+        fsum += f / 162.0f;
+        const float ff = f * f;
+        f2sum += ff / 162.0f;
+    }
+    const float m2 = fsum * fsum;
+    const float fac = sqrtf(f2sum - m2);
+    float sq = 0.0f;
+    unsigned char* __restrict__ so = sym_out + (size_t)idx * kNSymD;
+    for (int k = 0; k < kNSymD; ++k) {
+        const float4 p = P[k];
+        const float f = pr3[k] ? p.w - p.y : p.z - p.x;
+        float v = 50.0f * f / fac;
+        if (v > 127.0f) v = 127.0f;
+        if (v < -128.0f) v = -128.0f;
+        const float w = v + 128.0f;
+        const unsigned char b = (w == w) ? (unsigned char)(int)w : (unsigned char)0;
+        so[k] = b;
+        const float y = (float)b - 128.0f;
+        sq += y * y;
+    }
+    rms_out[idx] = sqrtf(sq / 162.0f);
+}
+
 // mode 0 epilogue: first lag (in scan order) with the strictly largest metric
 __global__ void pick_lag_kernel(FineState* __restrict__ items, int nitems,
                                 const float* __restrict__ sync_in, int nlag, int lagstep) {
@@ -197,6 +345,43 @@ void launch_demod(const float* dI, const float* dQ, int samples, const FineState
     hipLaunchKernelGGL(demod_kernel, dim3(nlag, nitems), dim3(192), 0, st, dI, dQ, samples, items, mode,
                        nlag, lagstep, ifmin, fstep, jitter, minsync1, sync_out, sym_out, rms_out, t.sync);
 }
+void launch_phasor_tables(const FineState* items, int nitems, int mode, float* tabs, hipStream_t st) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(phasor_table_kernel, dim3((kNSymD + 15) / 16, nitems), dim3(64), 0, st, items, mode, tabs);
+}
+
+// item_list_shared / item_list_own: indices into items[] of the candidates without / with drift
+void launch_demod_tiled(const float* dI, const float* dQ, int samples, const FineState* items, int nitems,
+                        const int* list_shared, int n_shared, const int* list_own, int n_own, int mode,
+                        int nlag, int lagstep, float minsync1, const float* tabs, float* pw,
+                        float* sync_out, unsigned char* sym_out, float* rms_out,
+                        const DeviceTables& t, hipStream_t st) {
+    if (nitems <= 0) return;
+    const int span = kSps * kTileSyms + lagstep * (nlag - 1);
+    const int pitch = (span + lagstep - 1) / lagstep + 1;
+    const size_t tile_bytes = (size_t)pitch * lagstep * sizeof(float2);
+    const int threads = ((kTileSyms * nlag + 63) / 64) * 64;
+    const dim3 block(threads);
+    float4* pw4 = reinterpret_cast<float4*>(pw);
+#define WSPR_LAUNCH_TILE(STEP)                                                                                   \
+    do {                                                                                                         \
+        if (n_shared > 0)                                                                                        \
+            hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSyms, n_shared), block,       \
+                               8192 + tile_bytes, st, dI, dQ, samples, items, list_shared, mode, nlag, minsync1, \
+                               tabs, pw4);                                                                       \
+        if (n_own > 0)                                                                                           \
+            hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSyms, n_own), block,         \
+                               kTileSyms * 8192 + tile_bytes, st, dI, dQ, samples, items, list_own, mode, nlag,  \
+                               minsync1, tabs, pw4);                                                             \
+    } while (0)
+    if (lagstep == 8) WSPR_LAUNCH_TILE(8);
+    else if (lagstep == 16) WSPR_LAUNCH_TILE(16);
+    else WSPR_LAUNCH_TILE(3);
+#undef WSPR_LAUNCH_TILE
+    hipLaunchKernelGGL(demod_metric_kernel, dim3((nitems * nlag + 63) / 64), dim3(64), 0, st, pw4, items, nitems,
+                       mode, nlag, minsync1, sync_out, sym_out, rms_out, t.sync);
+}
+
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(pick_lag_kernel, dim3((nitems + 63) / 64), dim3(64), 0, st, items, nitems, sync_in, nlag, lagstep);

@@ -89,6 +89,16 @@ void launch_demod(const float* dI, const float* dQ, int samples, const FineState
                   int mode, int nhyp, int lagstep, int ifmin, float fstep, const int* jitter,
                   float minsync1, float* sync_out, unsigned char* sym_out, float* rms_out,
                   const DeviceTables& t, hipStream_t st);
+// Tiled fast path for the wide searches.  FineState.pad must hold the index of the item's
+// first phasor table in `tabs` (1 table if drift == 0, else 162); list_shared/list_own are the
+// item indices without / with drift.  mode 0: nlag lags shift_coarse-128 + lagstep*m;
+// mode 2: 43 lags shift-63+3*m (lagstep must be 3).  pw: nitems*nlag*162 float4 of scratch.
+void launch_phasor_tables(const FineState* items, int nitems, int mode, float* tabs, hipStream_t st);
+void launch_demod_tiled(const float* dI, const float* dQ, int samples, const FineState* items, int nitems,
+                        const int* list_shared, int n_shared, const int* list_own, int n_own, int mode,
+                        int nlag, int lagstep, float minsync1, const float* tabs, float* pw,
+                        float* sync_out, unsigned char* sym_out, float* rms_out,
+                        const DeviceTables& t, hipStream_t st);
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st);
 void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nfreq, int ifmin,
                       float fstep, hipStream_t st);
