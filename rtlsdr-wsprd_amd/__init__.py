@@ -180,5 +180,5 @@ class BatchDecoder:
 def last_timings():
     ms = (C.c_double * 8)()
     n = lib().wspr_last_timings(C.addressof(ms), 8)
-    names = ["fft_sync_ms", "unused1", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms"]
+    names = ["fft_sync_ms", "host_bookkeeping_ms", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms"]
     return {names[i]: ms[i] for i in range(n)}

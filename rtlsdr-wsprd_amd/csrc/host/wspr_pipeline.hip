@@ -72,64 +72,77 @@ struct PinBuf {
 };
 
 // ------------------------------------------------------------- thread pool --
+// Fork-join pool for the short host phases between kernel launches (Fano attempts,
+// per-segment bookkeeping).  Those phases last tens of microseconds to a few
+// milliseconds and come in bursts, so workers spin briefly on the job epoch before
+// falling back to a condition variable, and work is handed out in chunks.
 class Pool {
 public:
     explicit Pool(int n) {
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> g(m_); quit_ = true; ++epoch_; }
+        quit_.store(true);
+        epoch_.fetch_add(1);
+        { std::lock_guard<std::mutex> g(m_); }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
     // runs fn(i) for i in [0, n); the calling thread participates
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
-        if (workers_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-        {
-            std::lock_guard<std::mutex> g(m_);
-            fn_ = &fn; total_ = n; next_.store(0); pending_ = (int)workers_.size(); ++epoch_;
+        if (workers_.empty() || n < 4) { for (int i = 0; i < n; ++i) fn(i); return; }
+        fn_ = &fn;
+        total_ = n;
+        chunk_ = std::max(1, n / (8 * ((int)workers_.size() + 1)));
+        next_.store(0);
+        active_.store((int)workers_.size());
+        epoch_.fetch_add(1);                       // publishes the job
+        if (sleepers_.load() > 0) {
+            { std::lock_guard<std::mutex> g(m_); }
+            cv_.notify_all();
         }
-        cv_.notify_all();
         drain();
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
+        while (active_.load(std::memory_order_acquire) != 0) cpu_relax();
         fn_ = nullptr;
     }
     int size() const { return (int)workers_.size() + 1; }
 
 private:
+    static void cpu_relax() { __builtin_ia32_pause(); }
     void drain() {
         for (;;) {
-            int i = next_.fetch_add(1);
-            if (i >= total_) break;
-            (*fn_)(i);
+            const int lo = next_.fetch_add(chunk_);
+            if (lo >= total_) break;
+            const int hi = std::min(total_, lo + chunk_);
+            for (int i = lo; i < hi; ++i) (*fn_)(i);
         }
     }
     void loop() {
         unsigned long seen = 0;
         for (;;) {
-            {
+            int spins = 0;
+            while (epoch_.load(std::memory_order_acquire) == seen) {
+                if (++spins < 20000) { cpu_relax(); continue; }
                 std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (quit_) return;
+                sleepers_.fetch_add(1);
+                cv_.wait(g, [&] { return epoch_.load() != seen; });
+                sleepers_.fetch_sub(1);
             }
+            seen = epoch_.load();
+            if (quit_.load()) return;
             drain();
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0) done_.notify_one();
-            }
+            active_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int total_ = 0, pending_ = 0;
-    unsigned long epoch_ = 0;
-    bool quit_ = false;
+    std::atomic<unsigned long> epoch_{0};
+    std::atomic<int> next_{0}, active_{0}, sleepers_{0};
+    std::atomic<bool> quit_{false};
+    int total_ = 0, chunk_ = 1;
 };
 
 // ---------------------------------------------------------------- context ----
@@ -138,7 +151,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists;
+        nvalid, decscratch, tabs, pw, lists, scrsync;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;
     int jitter_ladder[kMaxLags];
@@ -198,7 +211,8 @@ Context::Context() : d(new Impl) {
 
     int nthreads = (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
-    nthreads = std::max(1, std::min(nthreads, 128));
+    else nthreads = std::min(nthreads, 32);      // the host phases are short; more threads only add wake-up cost
+    nthreads = std::max(1, std::min(nthreads, 256));
     d->pool.reset(new Pool(nthreads - 1));
 }
 
@@ -418,7 +432,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
             int n_shared = 0, n_own = 0;
             const size_t ntabs = plan_tables(h_items, nw, h_lists, &n_shared, &n_own);
             int* d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
-            float* d_tabs = static_cast<float*>(c.tabs.need(ntabs * 2048 * 4));
+            float* d_tabs = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)nw * 5) * 2048 * 4));
             float* d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
             const int nh_max = std::max(nlag0, kMaxLags);
             float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
@@ -438,9 +452,13 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, nlag0, lagstep,
                                    0.0f, d_tabs, d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
                 launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
-                launch_demod(wi, wq, samples, d_items, nw, 1, 5, lagstep, -2, 0.1f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
-                launch_pick_freq(d_items, nw, d_sync, 5, -2, 0.1f, c.stream);
-                launch_demod(wi, wq, samples, d_items, nw, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), minsync1, d_sync, d_sym, d_rms, c.tab, c.stream);
+                {
+                    float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
+                    float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
+                    launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, lagstep,
+                                                    minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync, d_sym,
+                                                    d_rms, c.tab, c.stream);
+                }
                 HIP_OK(hipMemcpyAsync(h_items, d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
                 HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
                 HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
@@ -533,8 +551,18 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
             }
 
             // ---- host bookkeeping in candidate order (wsprd.c:768-822) ------------
-            std::vector<SubJob> jobs;
-            for (int i = 0; i < nw; ++i) {
+            // items of one segment are contiguous in the wave and must be handled in order;
+            // different segments are independent -> one pool task per segment
+            const auto t_b0 = std::chrono::steady_clock::now();
+            std::vector<int> group_start;
+            for (int i = 0; i < nw; ++i)
+                if (i == 0 || wave[i].seg != wave[i - 1].seg) group_start.push_back(i);
+            group_start.push_back(nw);
+            const int ngroups = (int)group_start.size() - 1;
+            std::vector<SubJob> job_of(nw);
+            std::vector<char> has_job(nw, 0);
+            c.pool->run(ngroups, [&](int g) {
+              for (int i = group_start[g]; i < group_start[g + 1]; ++i) {
                 WaveItem& w = wave[i];
                 const int s = w.seg;
                 if (stopped[s]) continue;
@@ -552,7 +580,8 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     SubJob jb{};
                     if (channel_symbols(call_loc_pow, hashtab_of(s), loctab_of(s), jb.sym)) {
                         jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
-                        jobs.push_back(jb);
+                        job_of[i] = jb;
+                        has_job[i] = 1;
                     } else {
                         stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
                         continue;
@@ -583,7 +612,11 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     snprintf(o->loc, sizeof o->loc, "%s", loc);
                     snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
                 }
-            }
+              }
+            });
+            std::vector<SubJob> jobs;
+            for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);
+            c.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b0).count();
 
             // ---- GPU: subtract everything that decoded in this wave ------------------
             if (!jobs.empty()) {
@@ -591,7 +624,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 SubJob* hj = static_cast<SubJob*>(c.h_jobs.need((size_t)nj * sizeof(SubJob)));
                 memcpy(hj, jobs.data(), (size_t)nj * sizeof(SubJob));
                 SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nj * sizeof(SubJob)));
-                float* scratch = static_cast<float*>(c.subscratch.need((size_t)nj * 4 * kSigLen * 4));
+                float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nj) * 4));
                 Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[4]);
                 upload(dj, hj, (size_t)nj * sizeof(SubJob), c.stream);
                 launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nj, scratch, c.tab, c.stream);
@@ -702,7 +735,7 @@ void Context::subtract_single(float* id, float* qd, long np, float f0, int shift
     memcpy(jb.sym, sym, kNSymD);
     SubJob* dj = static_cast<SubJob*>(c.jobs.need(sizeof jb));
     upload(dj, &jb, sizeof jb, c.stream);
-    float* scratch = static_cast<float*>(c.subscratch.need((size_t)4 * kSigLen * 4));
+    float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(1) * 4));
     launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), (int)np, dj, 1, scratch, c.tab, c.stream);
     store_host(id, qd, 1, samples, (size_t)samples);
 }

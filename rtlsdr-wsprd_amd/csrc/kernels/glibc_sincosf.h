@@ -46,11 +46,6 @@ WSPR_HD double mad(double b, double c, double a) {
 #endif
 }
 
-struct SinCosPoly {
-    double c0, c1, c2, c3, c4;   // cosine polynomial in x^2
-    double s1, s2, s3;           // sine polynomial in x^2
-};
-
 WSPR_HD uint32_t f32_bits(float f) {
     union { float f; uint32_t u; } v;
     v.f = f;
@@ -140,6 +135,36 @@ WSPR_HD float glibc_sincosf(float y, int which) {
         return sincos_poly(x * s, x * x, ((n + sign) & 2) != 0, n ^ which);
     }
     return y - y;                                              // inf/nan -> nan
+}
+
+// sinf(y) and cosf(y) with ONE shared argument reduction (the two libm calls reduce the
+// same argument identically, so sharing it changes nothing but the cost)
+WSPR_HD void glibc_sincosf_pair(float y, float* sn, float* cs) {
+    double x = y;
+    int n;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) { *sn = y; *cs = 1.0f; return; }
+        const double x2 = x * x;
+        *sn = sincos_poly(x, x2, false, 0);
+        *cs = sincos_poly(x, x2, false, 1);
+    } else if (abstop12(y) < abstop12(120.0f)) {
+        x = reduce_small(x, &n);
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        const double xs = x * s, x2 = x * x;
+        *sn = sincos_poly(xs, x2, (n & 2) != 0, n);
+        *cs = sincos_poly(xs, x2, (n & 2) != 0, n ^ 1);
+    } else if (abstop12(y) < 0x7f8) {
+        const uint32_t xi = f32_bits(y);
+        const int sign = (int)(xi >> 31);
+        x = reduce_big(xi, &n);
+        const int q = (n + sign) & 3;
+        const double s = (q == 1 || q == 2) ? -1.0 : 1.0;
+        const double xs = x * s, x2 = x * x;
+        *sn = sincos_poly(xs, x2, ((n + sign) & 2) != 0, n);
+        *cs = sincos_poly(xs, x2, ((n + sign) & 2) != 0, n ^ 1);
+    } else {
+        *sn = *cs = y - y;
+    }
 }
 
 WSPR_HD float glibc_sinf(float y) { return glibc_sincosf(y, 0); }

@@ -25,12 +25,12 @@ constexpr double kDf15 = 375.0 / 256.0 * 1.5;
 
 __global__ __launch_bounds__(192)
 void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                  const FineState* __restrict__ items, int mode, int nlag, int lagstep,
-                  int ifmin, float fstep, const int* __restrict__ jitter, float minsync1,
-                  float* __restrict__ sync_out, unsigned char* __restrict__ sym_out,
+                  const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
+                  int nlag, int lagstep, int ifmin, float fstep, const int* __restrict__ jitter,
+                  float minsync1, float* __restrict__ sync_out, unsigned char* __restrict__ sym_out,
                   float* __restrict__ rms_out, const unsigned char* __restrict__ pr3) {
     __shared__ float pw[kNSymD][4];
-    const int item = blockIdx.y, hyp = blockIdx.x;
+    const int item = item_list ? item_list[blockIdx.y] : (int)blockIdx.y, hyp = blockIdx.x;
     const FineState st = items[item];
 
     float f0;
@@ -166,7 +166,8 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
 //   demod_metric_kernel  one lane per (candidate, lag) folds the 162 symbols in order.
 // Same arithmetic per accumulator as demod_kernel => identical bits; ~8x less time
 // because loads are coalesced/LDS-served and tables are not recomputed per lag.
-constexpr int kTileSyms = 6;
+constexpr int kTileSymsShared = 9;    // 9 x 33 lags = 297 of 320 lanes; 28 KB of LDS
+constexpr int kTileSymsOwn = 6;       // per-symbol tables: 6 x 8 KB + tile
 
 __global__ __launch_bounds__(64)
 void phasor_table_kernel(const FineState* __restrict__ items, int mode, float* __restrict__ tabs) {
@@ -195,7 +196,7 @@ void phasor_table_kernel(const FineState* __restrict__ items, int mode, float* _
 }
 
 template <int STEP, bool SHARED>
-__global__ __launch_bounds__(320)
+__global__ __launch_bounds__(448)
 void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
                        int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out) {
@@ -203,6 +204,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const int item = item_list[blockIdx.y];
     const FineState st = items[item];
     if (mode == 2 && !(st.sync > minsync1)) return;
+    constexpr int kTileSyms = SHARED ? kTileSymsShared : kTileSymsOwn;
     const int i0 = blockIdx.x * kTileSyms, tid = threadIdx.x;
     const int lag0 = (mode == 0) ? st.shift_coarse - 128 : st.shift - 63;
     constexpr int ntab = SHARED ? 1 : kTileSyms;
@@ -299,6 +301,185 @@ void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restr
     rms_out[idx] = sqrtf(sq / 162.0f);
 }
 
+// -----------------------------------------------------------------------------
+// Frequency scan (mode 1) + first ladder rung (mode 2 at jitter 0) for candidates
+// without drift.  The five frequency hypotheses share the samples (same lag) and
+// each has ONE phasor table; the winning hypothesis' tone amplitudes are exactly
+// what mode 2 recomputes at (best freq, best lag), so the first soft-symbol vector
+// comes out of the same pass.  lane = (symbol, frequency).
+constexpr int kFreqSyms = 18;          // 18 x 5 = 90 of 128 lanes; 40 KB tables + 37 KB tile -> 2 WGs per CU
+constexpr int kNFreq = 5;
+constexpr int kFreqThreads = 128;
+
+__global__ __launch_bounds__(64)
+void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin,
+                        float fstep, float* __restrict__ tabs) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 4 * kNFreq) return;
+    const FineState st = items[item_list[slot]];
+    const int f = lane >> 2, tone = lane & 3;
+    const float f0 = st.freq + (float)(ifmin + f) * fstep;
+    const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)(0.0f - 81.0f) / (double)81.0f);
+    const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
+    const float dphi = (float)(kTwoPiDt * ((double)fp + off));
+    const float cd = glibc_cosf(dphi), sd = glibc_sinf(dphi);
+    float* __restrict__ t = tabs + ((size_t)slot * kNFreq + f) * 2048;
+    float c = 1.0f, s = 0.0f;
+    for (int j = 0; j < kSps; ++j) {
+        if (j > 0) {
+            const float a = c * cd, b = s * sd, e = c * sd, d = s * cd;
+            c = a - b;
+            s = e + d;
+        }
+        t[8 * j + tone] = c;
+        t[8 * j + 4 + tone] = s;
+    }
+}
+
+__global__ __launch_bounds__(kFreqThreads)
+void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                      const FineState* __restrict__ items, const int* __restrict__ item_list,
+                      const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int slot = blockIdx.y, tid = threadIdx.x;
+    const FineState st = items[item_list[slot]];
+    const int i0 = blockIdx.x * kFreqSyms;
+    float4* tab = reinterpret_cast<float4*>(smem);                         // [5][256][2]
+    float2* tile = reinterpret_cast<float2*>(smem + kNFreq * 8192);        // [18][257]
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * 512;
+    // prologue: issue the loads in batches so their latencies overlap
+    for (int e0 = 0; e0 < kNFreq * 512; e0 += kFreqThreads * 5) {
+        float4 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) v[u] = gt[e0 + u * kFreqThreads + tid];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) tab[e0 + u * kFreqThreads + tid] = v[u];
+    }
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int kbase = st.shift + kSps * i0;
+    for (int e0 = 0; e0 < kFreqSyms * kSps; e0 += kFreqThreads * 6) {
+        float2 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = kbase + e0 + u * kFreqThreads + tid;
+            const bool ok = (k > 0) && (k < np);
+            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * kFreqThreads + tid;
+            tile[(e >> 8) * 257 + (e & 255)] = v[u];
+        }
+    }
+    __syncthreads();
+    if (tid >= kFreqSyms * kNFreq) return;
+    const int il = tid / kNFreq, f = tid - il * kNFreq;
+    const float4* __restrict__ tb = tab + f * 512;
+    const float2* __restrict__ td = tile + il * 257;
+    float ai[4] = {0.0f, 0.0f, 0.0f, 0.0f}, aq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+    for (int j = 0; j < kSps; ++j) {
+        const float2 d = td[j];
+        const float4 c4 = tb[2 * j], s4 = tb[2 * j + 1];
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float m1 = d.x * c[t], m2 = d.y * s[t];
+            const float m3 = d.x * s[t], m4 = d.y * c[t];
+            ai[t] = (ai[t] + m1) + m2;
+            aq[t] = (aq[t] - m3) + m4;
+        }
+    }
+    float p[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float e1 = ai[t] * ai[t], e2 = aq[t] * aq[t];
+        p[t] = sqrtf(e1 + e2);
+    }
+    pw_out[((size_t)slot * kNFreq + f) * kNSymD + i0 + il] = make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// one wave per candidate: lanes 0..4 fold one frequency hypothesis each (162 symbols in
+// order), lane 0 applies the strict '>' pick of wsprd.c:227-232 and updates the state, then --
+// if worth a try -- forms the jitter-0 soft symbols from the winner's amplitudes
+__global__ __launch_bounds__(64)
+void freq_metric_kernel(const float4* __restrict__ pw, FineState* __restrict__ items,
+                        const int* __restrict__ item_list, int nshared, int ifmin, float fstep,
+                        float minsync1, float* __restrict__ sync_out, unsigned char* __restrict__ sym_out,
+                        float* __restrict__ rms_out, const unsigned char* __restrict__ pr3) {
+    __shared__ float4 P[kNFreq * kNSymD];
+    __shared__ float met[kNFreq];
+    __shared__ float fsym[kNSymD];
+    __shared__ float fac_s;
+    __shared__ int best_s;
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int item = item_list[slot];
+    for (int e = lane; e < kNFreq * kNSymD; e += 64) P[e] = pw[(size_t)slot * kNFreq * kNSymD + e];
+    __syncthreads();
+    if (lane < kNFreq) {
+        float ss = 0.0f, totp = 0.0f;
+        for (int k = 0; k < kNSymD; ++k) {
+            const float4 p = P[lane * kNSymD + k];
+            totp = totp + p.x + p.y + p.z + p.w;
+            const float cmet = (p.y + p.w) - (p.x + p.z);
+            ss = pr3[k] ? ss + cmet : ss - cmet;
+        }
+        met[lane] = ss / totp;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        FineState st = items[item];
+        const float fin = st.freq;
+        float best = -1e30f, fbest = 0.0f;
+        int bshift = 0, bf = -1;
+        for (int f = 0; f < kNFreq; ++f)
+            if (met[f] > best) { best = met[f]; fbest = fin + (float)(ifmin + f) * fstep; bshift = st.shift; bf = f; }
+        st.freq = fbest;
+        st.shift = bshift;
+        st.sync = best;
+        items[item] = st;
+        best_s = (best > minsync1) ? bf : -1;
+        if (best_s >= 0) sync_out[item] = best;
+    }
+    __syncthreads();
+    const int bf = best_s;
+    if (bf < 0) return;
+    // mode 2 at (fbest, shift): same accumulators as hypothesis bf (wsprd.c:219-225, 243-256)
+    for (int k = lane; k < kNSymD; k += 64) {
+        const float4 p = P[bf * kNSymD + k];
+        fsym[k] = pr3[k] ? p.w - p.y : p.z - p.x;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float fsum = 0.0f, f2sum = 0.0f;
+        for (int k = 0; k < kNSymD; ++k) {
+            const float f = fsym[k];
+            fsum += f / 162.0f;
+            const float ff = f * f;
+            f2sum += ff / 162.0f;
+        }
+        const float m2 = fsum * fsum;
+        fac_s = sqrtf(f2sum - m2);
+    }
+    __syncthreads();
+    const float fac = fac_s;
+    float sq = 0.0f;                 // sum of squares of small integers: exact in any order
+    for (int k = lane; k < kNSymD; k += 64) {
+        float v = 50.0f * fsym[k] / fac;
+        if (v > 127.0f) v = 127.0f;
+        if (v < -128.0f) v = -128.0f;
+        const float w = v + 128.0f;
+        const unsigned char b = (w == w) ? (unsigned char)(int)w : (unsigned char)0;
+        sym_out[(size_t)item * kNSymD + k] = b;
+        const float y = (float)b - 128.0f;
+        sq += y * y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) rms_out[item] = sqrtf(sq / 162.0f);
+}
+
 // mode 0 epilogue: first lag (in scan order) with the strictly largest metric
 __global__ void pick_lag_kernel(FineState* __restrict__ items, int nitems,
                                 const float* __restrict__ sync_in, int nlag, int lagstep) {
@@ -318,10 +499,11 @@ __global__ void pick_lag_kernel(FineState* __restrict__ items, int nitems,
 }
 
 // mode 1 epilogue: first frequency with the strictly largest metric
-__global__ void pick_freq_kernel(FineState* __restrict__ items, int nitems,
+__global__ void pick_freq_kernel(FineState* __restrict__ items, const int* __restrict__ item_list, int nitems,
                                  const float* __restrict__ sync_in, int nfreq, int ifmin, float fstep) {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= nitems) return;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nitems) return;
+    const int it = item_list ? item_list[pos] : pos;
     FineState st = items[it];
     const float fin = st.freq;                 // == freq_coarse unless mode 0 found nothing
     float best = -1e30f, fbest = 0.0f;
@@ -342,9 +524,42 @@ void launch_demod(const float* dI, const float* dQ, int samples, const FineState
                   float minsync1, float* sync_out, unsigned char* sym_out, float* rms_out,
                   const DeviceTables& t, hipStream_t st) {
     if (nitems <= 0 || nlag <= 0) return;
-    hipLaunchKernelGGL(demod_kernel, dim3(nlag, nitems), dim3(192), 0, st, dI, dQ, samples, items, mode,
-                       nlag, lagstep, ifmin, fstep, jitter, minsync1, sync_out, sym_out, rms_out, t.sync);
+    hipLaunchKernelGGL(demod_kernel, dim3(nlag, nitems), dim3(192), 0, st, dI, dQ, samples, items,
+                       (const int*)nullptr, mode, nlag, lagstep, ifmin, fstep, jitter, minsync1, sync_out,
+                       sym_out, rms_out, t.sync);
 }
+// Frequency scan (5 hypotheses at +-0.2 Hz, step 0.1) followed by the first ladder rung.
+// Drift-free candidates (list_shared) take the fused tiled path; drifting ones (list_own) the
+// general kernel.  Outputs: items[] updated (freq, sync), rung-0 sync/sym/rms at [item].
+void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int samples, FineState* items,
+                                     const int* list_shared, int n_shared, const int* list_own, int n_own,
+                                     int lagstep, float minsync1, const int* jitter0, float* tabs, float* pw,
+                                     float* scratch_sync, float* sync_out, unsigned char* sym_out,
+                                     float* rms_out, const DeviceTables& t, hipStream_t st) {
+    if (n_shared > 0) {
+        hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
+        constexpr size_t lds = kNFreq * 8192 + kFreqSyms * 257 * sizeof(float2);        // 77 KB
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(freq_tile_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(freq_tile_kernel, dim3(kNSymD / kFreqSyms, n_shared), dim3(kFreqThreads), lds, st, dI, dQ,
+                           samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
+        hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
+                           reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
+                           sync_out, sym_out, rms_out, t.sync);
+    }
+    if (n_own > 0) {
+        // scratch_sync is indexed [item][5] by the general kernel
+        hipLaunchKernelGGL(demod_kernel, dim3(kNFreq, n_own), dim3(192), 0, st, dI, dQ, samples, items, list_own, 1,
+                           kNFreq, lagstep, -2, 0.1f, (const int*)nullptr, 0.0f, scratch_sync, (unsigned char*)nullptr,
+                           (float*)nullptr, t.sync);
+        hipLaunchKernelGGL(pick_freq_kernel, dim3((n_own + 63) / 64), dim3(64), 0, st, items, list_own, n_own,
+                           scratch_sync, kNFreq, -2, 0.1f);
+        hipLaunchKernelGGL(demod_kernel, dim3(1, n_own), dim3(192), 0, st, dI, dQ, samples, items, list_own, 2, 1,
+                           lagstep, 0, 0.0f, jitter0, minsync1, sync_out, sym_out, rms_out, t.sync);
+    }
+}
+
 void launch_phasor_tables(const FineState* items, int nitems, int mode, float* tabs, hipStream_t st) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(phasor_table_kernel, dim3((kNSymD + 15) / 16, nitems), dim3(64), 0, st, items, mode, tabs);
@@ -357,22 +572,23 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                         float* sync_out, unsigned char* sym_out, float* rms_out,
                         const DeviceTables& t, hipStream_t st) {
     if (nitems <= 0) return;
-    const int span = kSps * kTileSyms + lagstep * (nlag - 1);
-    const int pitch = (span + lagstep - 1) / lagstep + 1;
-    const size_t tile_bytes = (size_t)pitch * lagstep * sizeof(float2);
-    const int threads = ((kTileSyms * nlag + 63) / 64) * 64;
-    const dim3 block(threads);
+    auto tile_bytes = [&](int syms) {
+        const int span = kSps * syms + lagstep * (nlag - 1);
+        const int pitch = (span + lagstep - 1) / lagstep + 1;
+        return (size_t)pitch * lagstep * sizeof(float2);
+    };
+    auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0)                                                                                        \
-            hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSyms, n_shared), block,       \
-                               8192 + tile_bytes, st, dI, dQ, samples, items, list_shared, mode, nlag, minsync1, \
-                               tabs, pw4);                                                                       \
+            hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
+                               threads(kTileSymsShared), 8192 + tile_bytes(kTileSymsShared), st, dI, dQ, samples, \
+                               items, list_shared, mode, nlag, minsync1, tabs, pw4);                             \
         if (n_own > 0)                                                                                           \
-            hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSyms, n_own), block,         \
-                               kTileSyms * 8192 + tile_bytes, st, dI, dQ, samples, items, list_own, mode, nlag,  \
-                               minsync1, tabs, pw4);                                                             \
+            hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSymsOwn, n_own),             \
+                               threads(kTileSymsOwn), kTileSymsOwn * 8192 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
+                               samples, items, list_own, mode, nlag, minsync1, tabs, pw4);                       \
     } while (0)
     if (lagstep == 8) WSPR_LAUNCH_TILE(8);
     else if (lagstep == 16) WSPR_LAUNCH_TILE(16);
@@ -389,8 +605,8 @@ void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nla
 void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nfreq, int ifmin,
                       float fstep, hipStream_t st) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(pick_freq_kernel, dim3((nitems + 63) / 64), dim3(64), 0, st, items, nitems, sync_in,
-                       nfreq, ifmin, fstep);
+    hipLaunchKernelGGL(pick_freq_kernel, dim3((nitems + 63) / 64), dim3(64), 0, st, items, (const int*)nullptr,
+                       nitems, sync_in, nfreq, ifmin, fstep);
 }
 
 }  // namespace wspr

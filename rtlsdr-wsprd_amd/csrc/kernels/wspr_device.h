@@ -99,11 +99,19 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                         int nlag, int lagstep, float minsync1, const float* tabs, float* pw,
                         float* sync_out, unsigned char* sym_out, float* rms_out,
                         const DeviceTables& t, hipStream_t st);
+// mode 1 (5 frequencies) + first ladder rung; see k4_demod.hip.  tabs: n_shared*5 tables,
+// pw: n_shared*5*162 float4, scratch_sync: nitems*5 floats.
+void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int samples, FineState* items,
+                                     const int* list_shared, int n_shared, const int* list_own, int n_own,
+                                     int lagstep, float minsync1, const int* jitter0, float* tabs, float* pw,
+                                     float* scratch_sync, float* sync_out, unsigned char* sym_out,
+                                     float* rms_out, const DeviceTables& t, hipStream_t st);
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st);
 void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nfreq, int ifmin,
                       float fstep, hipStream_t st);
+size_t subtract_scratch_floats(int njobs);
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
-                     float* scratch /* njobs * 5 * kSigLen floats */, const DeviceTables& t, hipStream_t st);
+                     float* scratch /* subtract_scratch_floats(njobs) */, const DeviceTables& t, hipStream_t st);
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
 void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
                      int* n_out, int32_t* scratch, hipStream_t st);
