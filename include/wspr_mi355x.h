@@ -116,8 +116,9 @@ int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int sa
                           size_t seg_stride, int coarse, int maxdrift, struct cand *cand_out,
                           int *npk_out, float *noise_out, float *smspec_out);
 /* Timing of the stages of the most recent batch call, milliseconds (HIP events on
- * the library's stream). Order: fft_bank, pick_peaks, coarse_sync, demod, subtract,
- * host_fano, total. Returns the number of values written. */
+ * the library's stream / host clock). Order: fft+sync stage, host bookkeeping, (unused), fine
+ * sync + demod, subtract, host Fano, total, then counts: Fano calls, Fano time-outs, Fano
+ * cycles. Returns the number of values written. */
 int wspr_last_timings(double *ms, int capacity);
 /* Times `iters` back-to-back launches of the FFT+sync stage (K1,K2,K3) on resident
  * data with HIP events; returns average ms per launch of each kernel in ms[0..2]. */

@@ -178,7 +178,8 @@ class BatchDecoder:
 
 
 def last_timings():
-    ms = (C.c_double * 8)()
-    n = lib().wspr_last_timings(C.addressof(ms), 8)
-    names = ["fft_sync_ms", "host_bookkeeping_ms", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms"]
+    ms = (C.c_double * 12)()
+    n = lib().wspr_last_timings(C.addressof(ms), 12)
+    names = ["fft_sync_ms", "host_bookkeeping_ms", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms",
+             "fano_calls", "fano_timeouts", "fano_cycles"]
     return {names[i]: ms[i] for i in range(n)}

@@ -72,77 +72,79 @@ struct PinBuf {
 };
 
 // ------------------------------------------------------------- thread pool --
-// Fork-join pool for the short host phases between kernel launches (Fano attempts,
-// per-segment bookkeeping).  Those phases last tens of microseconds to a few
-// milliseconds and come in bursts, so workers spin briefly on the job epoch before
-// falling back to a condition variable, and work is handed out in chunks.
+// Fork-join pool for the host phases between kernel launches (Fano attempts,
+// per-segment bookkeeping).  A job is an immutable heap object with two counters;
+// completion is "all tasks done", never "all workers checked in", so threads that
+// wake up late cost nothing, and a late thread holding an exhausted old job can never
+// touch a newer one.  Workers spin for a few tens of microseconds and then sleep.
 class Pool {
+    struct Job {
+        const std::function<void(int)>* fn;
+        int total, chunk;
+        std::atomic<int> next{0}, done{0};
+    };
+
 public:
     explicit Pool(int n) {
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
     }
     ~Pool() {
         quit_.store(true);
-        epoch_.fetch_add(1);
-        { std::lock_guard<std::mutex> g(m_); }
+        { std::lock_guard<std::mutex> g(m_); ++epoch_; }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
-    // runs fn(i) for i in [0, n); the calling thread participates
-    void run(int n, const std::function<void(int)>& fn) {
+    // runs fn(i) for i in [0, n); the calling thread participates.
+    // chunk = indices handed out per grab; 0 = automatic (many cheap, uniform tasks)
+    void run(int n, const std::function<void(int)>& fn, int chunk = 0) {
         if (n <= 0) return;
         if (workers_.empty() || n < 4) { for (int i = 0; i < n; ++i) fn(i); return; }
-        fn_ = &fn;
-        total_ = n;
-        chunk_ = std::max(1, n / (8 * ((int)workers_.size() + 1)));
-        next_.store(0);
-        active_.store((int)workers_.size());
-        epoch_.fetch_add(1);                       // publishes the job
-        if (sleepers_.load() > 0) {
-            { std::lock_guard<std::mutex> g(m_); }
-            cv_.notify_all();
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->total = n;
+        job->chunk = chunk > 0 ? chunk : std::max(1, n / (8 * ((int)workers_.size() + 1)));
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = job;
+            ++epoch_;
         }
-        drain();
-        while (active_.load(std::memory_order_acquire) != 0) cpu_relax();
-        fn_ = nullptr;
+        cv_.notify_all();
+        drain(*job);
+        while (job->done.load(std::memory_order_acquire) < n) cpu_relax();
     }
     int size() const { return (int)workers_.size() + 1; }
 
 private:
     static void cpu_relax() { __builtin_ia32_pause(); }
-    void drain() {
+    static void drain(Job& j) {
         for (;;) {
-            const int lo = next_.fetch_add(chunk_);
-            if (lo >= total_) break;
-            const int hi = std::min(total_, lo + chunk_);
-            for (int i = lo; i < hi; ++i) (*fn_)(i);
+            const int lo = j.next.fetch_add(j.chunk);
+            if (lo >= j.total) break;
+            const int hi = std::min(j.total, lo + j.chunk);
+            for (int i = lo; i < hi; ++i) (*j.fn)(i);
+            j.done.fetch_add(hi - lo, std::memory_order_release);
         }
     }
     void loop() {
         unsigned long seen = 0;
         for (;;) {
-            int spins = 0;
-            while (epoch_.load(std::memory_order_acquire) == seen) {
-                if (++spins < 20000) { cpu_relax(); continue; }
+            std::shared_ptr<Job> job;
+            {
                 std::unique_lock<std::mutex> g(m_);
-                sleepers_.fetch_add(1);
-                cv_.wait(g, [&] { return epoch_.load() != seen; });
-                sleepers_.fetch_sub(1);
+                cv_.wait(g, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (quit_.load()) return;
+                job = job_;
             }
-            seen = epoch_.load();
-            if (quit_.load()) return;
-            drain();
-            active_.fetch_sub(1, std::memory_order_release);
+            if (job) drain(*job);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
-    const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<unsigned long> epoch_{0};
-    std::atomic<int> next_{0}, active_{0}, sleepers_{0};
+    std::shared_ptr<Job> job_;
+    unsigned long epoch_ = 0;
     std::atomic<bool> quit_{false};
-    int total_ = 0, chunk_ = 1;
 };
 
 // ---------------------------------------------------------------- context ----
@@ -153,12 +155,14 @@ struct Context::Impl {
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
         nvalid, decscratch, tabs, pw, lists, scrsync;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
-    std::unique_ptr<Pool> pool;
+    std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
+    std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
     int jitter_ladder[kMaxLags];
     // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
-    double t_ms[8] = {0};
+    double t_ms[12] = {0};           // stage times (ms) and Fano statistics of the last batch
+    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
@@ -210,10 +214,13 @@ Context::Context() : d(new Impl) {
     d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
 
     int nthreads = (int)std::thread::hardware_concurrency();
+    // default: one thread per physical core (SMT siblings do not help the integer-bound Fano
+    // search and oversubscription hurts the thread that drives the GPU)
+    nthreads = std::max(1, nthreads / 2);
     if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
-    else nthreads = std::min(nthreads, 32);      // the host phases are short; more threads only add wake-up cost
     nthreads = std::max(1, std::min(nthreads, 256));
-    d->pool.reset(new Pool(nthreads - 1));
+    d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
+    d->bigpool.reset(new Pool(nthreads - 1));
 }
 
 Context::~Context() {}
@@ -225,7 +232,7 @@ Context& Context::get() {
 
 hipStream_t Context::stream() { return d->stream; }
 const DeviceTables& Context::tables() { return d->tab; }
-int Context::host_threads() { return d->pool->size(); }
+int Context::host_threads() { return d->bigpool->size(); }
 
 float* Context::work_i(int nseg) { return static_cast<float*>(d->iqI.need((size_t)nseg * kIqStride * 4)); }
 float* Context::work_q(int nseg) { return static_cast<float*>(d->iqQ.need((size_t)nseg * kIqStride * 4)); }
@@ -340,6 +347,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                              int max_results, int* n_results) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
+    c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     for (int s = 0; s < nseg; ++s) n_results[s] = 0;
     const int blocks = 4 * (samples / kFftSize) - 1;
@@ -468,7 +476,10 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
 
             // ---- host: first rung of the jitter ladder ----------------------------
             const auto t_f0 = std::chrono::steady_clock::now();
-            c.pool->run(nw, [&](int i) {
+            // a candidate that passes the gates but does not decode costs a full time-out here
+            // (milliseconds) while a decode costs microseconds: one task per grab, all threads
+            Pool& pool0 = (nw >= 256) ? *c.bigpool : *c.pool;
+            pool0.run(nw, [&](int i) {
                 WaveItem& w = wave[i];
                 w.fine = h_items[i];
                 w.worth = w.fine.sync > minsync1;
@@ -483,8 +494,9 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     memset(w.decdata, 0, sizeof w.decdata);
                     const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
                     w.decoded = (nd == 0);
+                    c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++;
                 }
-            });
+            }, nw >= 256 ? 1 : 0);
             c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
 
             // ---- remaining rungs, only for candidates that still need them --------
@@ -519,8 +531,13 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 std::vector<Attempt> att((size_t)na * njit_rest);
                 std::vector<std::atomic<int>> first(na);
                 for (auto& f : first) f.store(njit_rest);
-                c.pool->run(na * njit_rest, [&](int idx) {
-                    const int a = idx / njit_rest, r = idx % njit_rest;
+                Pool& fpool = (na * njit_rest >= 256) ? *c.bigpool : *c.pool;
+                // rung-major order and one task per grab: a time-out costs ~810 000 decoder cycles
+                // (milliseconds) while a success costs microseconds, so costs are heavy-tailed; low
+                // rungs finish first and cancel the higher rungs of the same candidate
+                fpool.run(na * njit_rest, [&](int task) {
+                    const int r = task / na, a = task % na;
+                    const int idx = a * njit_rest + r;
                     Attempt& at = att[idx];
                     at.ok = 0;
                     if (r > first[a].load()) return;           // an earlier rung already decoded
@@ -531,12 +548,14 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     deinterleave162(sym);
                     unsigned metric, maxnp;
                     memset(at.data, 0, sizeof at.data);
-                    if (fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles) == 0) {
+                    const int nd = fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles);
+                    c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++;
+                    if (nd == 0) {
                         at.ok = 1;
                         int cur = first[a].load();
                         while (r < cur && !first[a].compare_exchange_weak(cur, r)) {}
                     }
-                });
+                }, 1);
                 for (int a = 0; a < na; ++a) {
                     const int r = first[a].load();
                     if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
@@ -646,11 +665,14 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
         }
     }
     c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
+    c.t_ms[7] = (double)c.n_fano.load();
+    c.t_ms[8] = (double)c.n_timeout.load();
+    c.t_ms[9] = (double)c.n_cycles.load();
     return 0;
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 7);
+    const int n = std::min(cap, 10);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }
