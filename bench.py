@@ -87,12 +87,24 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
     return I, Q, expected
 
 
+def usable_cpus():
+    """Hardware threads capped by the cgroup CPU quota (the GPU box gives each slot a slice)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
     """Oracle (CPU restatement, oracle/liboracle.so) on a bounded sample of the SAME segments."""
     import oracle_lib as ol
     from concurrent.futures import ThreadPoolExecutor
     ol.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     t = time.perf_counter()
     ol.decode(I_host[0], Q_host[0], NS)
     one = time.perf_counter() - t                       # single-core seconds per segment
@@ -108,8 +120,9 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
         res = list(ex.map(run, range(n)))
     wall = time.perf_counter() - t
     return {"value": n / wall, "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": "%d of the benchmarked segments, oracle/liboracle.so (gcc -O3, scalar C), %d threads; "
-                      "single core %.1f segments/s" % (n, cores, 1.0 / one)}, res
+            "sample": "%d of the benchmarked segments, oracle/liboracle.so (gcc -O3, scalar C), %d threads = the "
+                      "CPUs this container may use (cgroup quota; host has %d hw threads); single core %.1f "
+                      "segments/s" % (n, cores, os.cpu_count() or 0, 1.0 / one)}, res
 
 
 def main():
@@ -128,7 +141,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     # host Fano pool: share the host's cores between the ranks of this node
-    os.environ.setdefault("WSPR_HOST_THREADS", str(max(8, (os.cpu_count() or 16) // 2 // max(1, world))))
+    os.environ.setdefault("WSPR_HOST_THREADS", str(max(2, usable_cpus() // max(1, world))))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -219,7 +232,8 @@ def main():
                                    "defaults (npasses 2, subtraction on, quickmode off)",
                        "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0"},
             "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
-            "stage_ms_last_step": timings, "host_threads": os.cpu_count(),
+            "stage_ms_last_step": timings, "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
+            "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

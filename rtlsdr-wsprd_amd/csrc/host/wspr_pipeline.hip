@@ -166,6 +166,25 @@ struct Context::Impl {
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
+// CPUs this process may actually use: hardware threads capped by the cgroup CPU quota
+// (a container on a shared GPU node typically owns a slice; running more runnable threads
+// than the quota gets the whole process throttled)
+static int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    long quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2
+        char q[32] = {0};
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f1, "%ld", &quota) != 1) quota = -1; fclose(f1); }
+        if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%ld", &period) != 1) period = -1; fclose(f2); }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1L, (quota + period - 1) / period));
+    return n;
+}
+
 static void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
 }
@@ -213,10 +232,7 @@ Context::Context() : d(new Impl) {
     d->tab.min_snr = powf(10.0, -8.0 / 10.0);                                        // wsprd.c:590
     d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
 
-    int nthreads = (int)std::thread::hardware_concurrency();
-    // default: one thread per physical core (SMT siblings do not help the integer-bound Fano
-    // search and oversubscription hurts the thread that drives the GPU)
-    nthreads = std::max(1, nthreads / 2);
+    int nthreads = usable_cpus();
     if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
     nthreads = std::max(1, std::min(nthreads, 256));
     d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
