@@ -152,6 +152,15 @@ int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int sa
     } catch (const std::exception& e) { return fail("wspr_bench_fft_sync", e); }
 }
 
+int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
+    try {
+        Context& c = Context::get();
+        for (int i = 0; i < iters; ++i) wspr::launch_calib_copy((const float*)d_src, (float*)d_dst, nfloats, c.stream());
+        c.sync();
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
+}
+
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {
     try {

@@ -153,7 +153,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists, scrsync;
+        nvalid, decscratch, tabs, pw, lists, scrsync, psavg;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
@@ -294,7 +294,8 @@ void Context::run_fft_sync(int nseg, int samples, int maxdrift, bool coarse, con
     DevCand* cand = static_cast<DevCand*>(d->cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
     int* npk = static_cast<int*>(d->npk.need((size_t)nseg * 4));
     launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), d_seglist, nactive, samples, ps, d->tab, d->stream);
-    launch_pick_peaks(ps, d_seglist, nactive, blocks, cand, npk, noise_out, smspec_out, d->tab, d->stream);
+    float* psavg = static_cast<float*>(d->psavg.need((size_t)nseg * kPsStride * 4));
+    launch_pick_peaks(ps, d_seglist, nactive, blocks, psavg, cand, npk, noise_out, smspec_out, d->tab, d->stream);
     if (coarse) launch_coarse_sync(ps, d_seglist, nactive, blocks, cand, npk, maxdrift, d->tab, d->stream);
 }
 
@@ -705,7 +706,8 @@ int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
         HIP_OK(hipEventRecord(ev[4 * it + 0], d->stream));
         launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), nullptr, nseg, samples, ps, d->tab, d->stream);
         HIP_OK(hipEventRecord(ev[4 * it + 1], d->stream));
-        launch_pick_peaks(ps, nullptr, nseg, blocks, cand, npk, nullptr, nullptr, d->tab, d->stream);
+        launch_pick_peaks(ps, nullptr, nseg, blocks, static_cast<float*>(d->psavg.need((size_t)nseg * kPsStride * 4)),
+                          cand, npk, nullptr, nullptr, d->tab, d->stream);
         HIP_OK(hipEventRecord(ev[4 * it + 2], d->stream));
         launch_coarse_sync(ps, nullptr, nseg, blocks, cand, npk, 4, d->tab, d->stream);
         HIP_OK(hipEventRecord(ev[4 * it + 3], d->stream));

@@ -18,13 +18,13 @@
 // The butterfly arithmetic (u+v, (u-v)*w with separately rounded products) is the
 // same as the CPU oracle's orc_fft512(), so results are bit-identical to it.
 #include "wspr_device.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
 namespace wspr {
 
 namespace {
-constexpr int kBlocksPerWave = 8;
 constexpr int kWavesPerWg    = 4;
 constexpr int kTile          = 576;     // complex words of LDS per wave
 
@@ -45,8 +45,41 @@ __device__ __forceinline__ void pass3(float2 (&x)[8], const float2 (&tw)[7]) {
     bfly(x[0], x[1], tw[6]); bfly(x[2], x[3], tw[6]); bfly(x[4], x[5], tw[6]); bfly(x[6], x[7], tw[6]);
 }
 
+// The last three stages only meet the twiddles 1, -i and (1-i)/sqrt2, (-1-i)/sqrt2.  Written
+// out, the general butterfly reduces to the forms below with every surviving operation rounded
+// exactly as in the general formula (x*1 = x, x*0 = +-0 adds exactly, -(a*b) = a*(-b)), so the
+// bits are those of the general radix-2 butterfly the CPU oracle runs.
+__device__ __forceinline__ void bfly_one(float2& u, float2& v) {            // w = 1
+    const float dr = u.x - v.x, di = u.y - v.y;
+    u.x = u.x + v.x; u.y = u.y + v.y;
+    v.x = dr; v.y = di;
+}
+__device__ __forceinline__ void bfly_mi(float2& u, float2& v) {             // w = -i
+    const float dr = u.x - v.x, di = u.y - v.y;
+    u.x = u.x + v.x; u.y = u.y + v.y;
+    v.x = di; v.y = -dr;
+}
+__device__ __forceinline__ void bfly_w8(float2& u, float2& v, float c) {    // w = (c, -c)
+    const float dr = u.x - v.x, di = u.y - v.y;
+    u.x = u.x + v.x; u.y = u.y + v.y;
+    const float a = dr * c, b = di * c;
+    v.x = a + b; v.y = b - a;
+}
+__device__ __forceinline__ void bfly_w83(float2& u, float2& v, float c) {   // w = (-c, -c)
+    const float dr = u.x - v.x, di = u.y - v.y;
+    u.x = u.x + v.x; u.y = u.y + v.y;
+    const float a = dr * c, b = di * c;
+    v.x = b - a; v.y = -a - b;
+}
+__device__ __forceinline__ void pass3_last(float2 (&x)[8], float c) {
+    bfly_one(x[0], x[4]); bfly_w8(x[1], x[5], c); bfly_mi(x[2], x[6]); bfly_w83(x[3], x[7], c);
+    bfly_one(x[0], x[2]); bfly_mi(x[1], x[3]);    bfly_one(x[4], x[6]); bfly_mi(x[5], x[7]);
+    bfly_one(x[0], x[1]); bfly_one(x[2], x[3]);   bfly_one(x[4], x[5]); bfly_one(x[6], x[7]);
+}
+
 __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 
+template <int kBlocksPerWave>
 __global__ __launch_bounds__(256)
 void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                      const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
@@ -72,8 +105,7 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                            twiddle[2 * lane], twiddle[128 + 2 * lane], twiddle[4 * lane]};
     const float2 twB[7] = {twiddle[8 * c], twiddle[64 + 8 * c], twiddle[128 + 8 * c], twiddle[192 + 8 * c],
                            twiddle[16 * c], twiddle[128 + 16 * c], twiddle[32 * c]};
-    const float2 twC[7] = {twiddle[0], twiddle[64], twiddle[128], twiddle[192],
-                           twiddle[0], twiddle[128], twiddle[0]};
+    const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
 
     float ri[8], rq[8];
 #pragma unroll
@@ -113,7 +145,7 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
         for (int r = 0; r < 8; ++r) x[r] = X[9 * lane + r];
         __builtin_amdgcn_wave_barrier();
 
-        pass3(x, twC);
+        pass3_last(x, w8);
 
         // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane)
         float* __restrict__ row = out + (size_t)t * kPsStride;
@@ -132,13 +164,36 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
 }
 }  // namespace
 
+// Calibration helper for the HBM PMC counters: a plain 4-byte-per-lane stream copy, the
+// same access width as K1's loads/stores, over a known number of bytes.
+namespace {
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, st, src, dst, n);
+}
+
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                      int samples, float* ps, const DeviceTables& t, hipStream_t st) {
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (blocks <= 0 || nseg_active <= 0) return;
-    const int per_wg = kBlocksPerWave * kWavesPerWg;
-    dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);
-    hipLaunchKernelGGL(fft_bank_kernel, grid, dim3(256), 0, st, dI, dQ, seg_list, blocks, ps, t.window, t.twiddle);
+    // consecutive FFTs per wave: longer runs re-read less input (run of R blocks loads R+3 hops)
+    static const int bpw = [] { const char* e = getenv("WSPR_K1_BLOCKS_PER_WAVE"); return e ? atoi(e) : 8; }();
+#define WSPR_K1(R)                                                                                          \
+    do {                                                                                                    \
+        const int per_wg = R * kWavesPerWg;                                                                 \
+        dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);                                             \
+        hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), 0, st, dI, dQ, seg_list, blocks, ps,        \
+                           t.window, t.twiddle);                                                            \
+    } while (0)
+    if (bpw == 12) WSPR_K1(12);
+    else if (bpw == 16) WSPR_K1(16);
+    else if (bpw == 22) WSPR_K1(22);
+    else if (bpw == 4) WSPR_K1(4);
+    else WSPR_K1(8);
+#undef WSPR_K1
 }
 
 }  // namespace wspr

@@ -17,9 +17,34 @@ namespace {
 constexpr double kHalfDf = 375.0 / 256.0 / 2.0;      // (DF / 2.0), wsprd.c:615
 
 // ------------------------------------------------------------------ K2 ------
-// One workgroup per segment.
+// K2a: time-averaged spectrum.  lane = bin, serial over the 347 time blocks in reference order
+// (wsprd.c:556-561).  Pure streaming read of ps (the HBM-bound part of K2): one wave per 64 bins
+// so that thousands of independent waves keep the memory system busy.
+__global__ __launch_bounds__(64)
+void time_average_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
+                         float* __restrict__ psavg) {
+    const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
+    const int col = 4 * (blockIdx.x * 64 + threadIdx.x);          // 4 bins (16 B) per lane
+    if (col >= kPsBins) return;                                     // columns 417..431 of a row are padding
+    const float4* __restrict__ P = reinterpret_cast<const float4*>(ps + (size_t)seg * kMaxBlocks * kPsStride + col);
+    constexpr int kRow4 = kPsStride / 4;
+    // four independent serial chains per lane; batch the loads ahead of the adds
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int t = 0;
+    for (; t + 8 <= blocks; t += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = P[(size_t)(t + u) * kRow4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; t < blocks; ++t) { const float4 v = P[(size_t)t * kRow4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    *reinterpret_cast<float4*>(psavg + (size_t)seg * kPsStride + col) = acc;
+}
+
+// K2b: one workgroup per segment, everything after the time average (wsprd.c:565-631)
 __global__ __launch_bounds__(512)
-void pick_peaks_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
+void pick_peaks_kernel(const float* __restrict__ psavg, const int* __restrict__ seg_list,
                        DevCand* __restrict__ cand, int* __restrict__ npk_out,
                        float* __restrict__ noise_out, float* __restrict__ smspec_out,
                        float min_snr, float floor_snr) {
@@ -33,23 +58,7 @@ void pick_peaks_kernel(const float* __restrict__ ps, const int* __restrict__ seg
 
     const int tid = threadIdx.x;
     const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
-    const float* __restrict__ P = ps + (size_t)seg * kMaxBlocks * kPsStride;
-
-    // time-averaged spectrum: lane = bin, serial over time (wsprd.c:556-561)
-    if (tid < kPsBins) {
-        // the adds are a serial chain (reference order); batch the loads ahead of them
-        float acc = 0.0f;
-        int t = 0;
-        for (; t + 16 <= blocks; t += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = P[(size_t)(t + u) * kPsStride + tid];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc += v[u];
-        }
-        for (; t < blocks; ++t) acc += P[(size_t)t * kPsStride + tid];
-        avg[tid] = acc;
-    }
+    if (tid < kPsBins) avg[tid] = psavg[(size_t)seg * kPsStride + tid];
     if (tid == 0) noise_s = 0.0f;
     __syncthreads();
 
@@ -86,21 +95,35 @@ void pick_peaks_kernel(const float* __restrict__ ps, const int* __restrict__ seg
     }
     __syncthreads();
 
-    // strict local maxima, first 200 only, then the +-110 Hz window (wsprd.c:608-629)
+    // strict local maxima, first 200 only, then the +-110 Hz window (wsprd.c:608-629): ordered
+    // compaction with wave ballots (the reference walks j = 1..409 once)
+    __shared__ unsigned long long bal_peak[8], bal_keep[8];
+    const int wv = tid >> 6, ln = tid & 63;
+    const unsigned long long below = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
+    bool peak = false;
+    if (tid >= 1 && tid < kSmooth - 1) {
+        const float v = nrm[tid];
+        peak = (v > nrm[tid - 1]) && (v > nrm[tid + 1]);
+    }
+    const unsigned long long bp = __ballot(peak);
+    if (ln == 0) bal_peak[wv] = bp;
+    __syncthreads();
+    int found_before = __popcll(bp & below);
+    for (int q = 0; q < wv; ++q) found_before += __popcll(bal_peak[q]);
+    const float fj = (float)((double)(tid - 205) * kHalfDf);
+    const bool keep = peak && (found_before < kMaxCand) && (fj >= -110.0f) && (fj <= 110.0f);
+    const unsigned long long bk = __ballot(keep);
+    if (ln == 0) bal_keep[wv] = bk;
+    __syncthreads();
+    if (keep) {
+        int idx = __popcll(bk & below);
+        for (int q = 0; q < wv; ++q) idx += __popcll(bal_keep[q]);
+        pk_bin[idx] = tid;
+        pk_snr[idx] = (float)(10.0 * (double)log10f(nrm[tid]) - (double)26.3f);
+    }
     if (tid == 0) {
-        int found = 0, kept = 0;
-        for (int j = 1; j < kSmooth - 1; ++j) {
-            const float v = nrm[j];
-            if (v > nrm[j - 1] && v > nrm[j + 1] && found < kMaxCand) {
-                ++found;
-                const float f = (float)((double)(j - 205) * kHalfDf);
-                if (f >= -110.0f && f <= 110.0f) {
-                    pk_bin[kept] = j;
-                    pk_snr[kept] = (float)(10.0 * (double)log10f(v) - (double)26.3f);
-                    ++kept;
-                }
-            }
-        }
+        int kept = 0;
+        for (int q = 0; q < 8; ++q) kept += __popcll(bal_keep[q]);
         kept_s = kept;
         npk_out[seg] = kept;
         if (noise_out) noise_out[seg] = noise;
@@ -212,11 +235,13 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
 }
 }  // namespace
 
-void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks,
+void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
                        DevCand* cand, int* npk, float* noise_out, float* smspec_out,
                        const DeviceTables& t, hipStream_t st) {
     if (nseg_active <= 0) return;
-    hipLaunchKernelGGL(pick_peaks_kernel, dim3(nseg_active), dim3(512), 0, st, ps, seg_list, blocks,
+    hipLaunchKernelGGL(time_average_kernel, dim3((kPsBins + 255) / 256, nseg_active), dim3(64), 0, st, ps, seg_list,
+                       blocks, psavg);
+    hipLaunchKernelGGL(pick_peaks_kernel, dim3(nseg_active), dim3(512), 0, st, psavg, seg_list,
                        cand, npk, noise_out, smspec_out, t.min_snr, t.floor_snr);
 }
 

@@ -74,7 +74,9 @@ struct DeviceTables {
 // ---- launchers (all asynchronous on `st`) ----------------------------------
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                      int samples, float* ps, const DeviceTables& t, hipStream_t st);
-void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks,
+void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
+// psavg: scratch, nseg * kPsStride floats (time-averaged spectrum per segment)
+void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
                        DevCand* cand, int* npk, float* noise_out, float* smspec_out,
                        const DeviceTables& t, hipStream_t st);
 void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, int blocks,
