@@ -87,6 +87,53 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
     return I, Q, expected
 
 
+RAW_BYTES = 576_000_000                      # 120 s x 2.4 Msps x 2 bytes
+
+
+def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0):
+    """Config-5 raw segments: unsigned 8-bit interleaved I/Q at 2.4 Msps.  The config-2 baseband
+    frame (375 sps) is held for 6400 samples, moved to -600 kHz (the tuner sits fs/4 above the band:
+    rtlsdr_wsprd.c:1112; the receiver's (1, j, -1, -j) mixer brings it back), buried in wide-band
+    noise of `noise_lsb` LSB rms per rail and quantised around 127.5."""
+    import synth
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    nsamp = RAW_BYTES // 2
+    raw = torch.empty(nseg, RAW_BYTES, device=dev, dtype=torch.uint8)
+    df, dt = 375.0 / 256.0, 1.0 / 375.0
+    # in-band noise power in 2500 Hz of complex noise with sigma per rail at 2.4 Msps
+    n2500 = 2.0 * noise_lsb ** 2 * 2500.0 / 2.4e6
+    amp = float(np.sqrt(n2500 * 10.0 ** (snr_db / 10.0)))
+    expected = []
+    chunk = 6400 * 1500                                   # 9.6 M samples per chunk
+    for s in range(nseg):
+        msg = synth.message_for(int(rng.integers(0, 1 << 20)))
+        sym = w.get_wspr_channel_symbols(msg)[1].astype(np.float64)
+        f0 = rng.uniform(-100.0, 100.0)
+        t0 = 2.0 + rng.uniform(-1.0, 1.0)
+        dphi = np.repeat(2.0 * np.pi * dt * (f0 + (sym - 1.5) * df), 256)
+        phi = np.concatenate(([0.0], np.cumsum(dphi)[:-1]))
+        bb = np.zeros(45000, np.complex128)
+        start = int(round(t0 / dt))
+        bb[start:start + 41472] = amp * np.exp(1j * phi)[:max(0, min(41472, 45000 - start))]
+        bbr = torch.from_numpy(np.ascontiguousarray(bb.real)).float().to(dev)
+        bbi = torch.from_numpy(np.ascontiguousarray(bb.imag)).float().to(dev)
+        out = raw[s].view(nsamp, 2)
+        for c0 in range(0, nsamp, chunk):
+            n = torch.arange(c0, min(nsamp, c0 + chunk), device=dev)
+            m = torch.div(n, 6400, rounding_mode="floor")
+            xr, xi = bbr[m], bbi[m]
+            ph = n & 3                                      # x * (-j)^n
+            zr = torch.where(ph == 0, xr, torch.where(ph == 1, xi, torch.where(ph == 2, -xr, -xi)))
+            zi = torch.where(ph == 0, xi, torch.where(ph == 1, -xr, torch.where(ph == 2, -xi, xr)))
+            nz = torch.randn(n.numel(), 2, device=dev, generator=g) * noise_lsb
+            out[c0:c0 + n.numel(), 0] = (127.5 + zr + nz[:, 0]).round().clamp(0, 255).to(torch.uint8)
+            out[c0:c0 + n.numel(), 1] = (127.5 + zi + nz[:, 1]).round().clamp(0, 255).to(torch.uint8)
+        expected.append([synth.expected_text(msg)])
+    return raw, expected
+
+
 def usable_cpus():
     """Hardware threads capped by the cgroup CPU quota (the GPU box gives each slot a slice)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -131,9 +178,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--segments", type=int, default=None, help="segments per GPU (default: the config's)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE.json configs index: 2 = configs[1] (1024 seg x 1 signal, -20 dB; the metric's "
-                         "workload), 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB)")
+                         "workload), 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB), 5 = configs[4] (raw 2.4 Msps "
+                         "u8 IQ through the on-GPU decimator; --segments raw segments resident per step, default 64)")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -151,14 +199,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    nseg = args.segments or (1024 if args.config == 2 else 8192)
+    nseg = args.segments or {2: 1024, 3: 8192, 5: 64}[args.config]
     assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
     if args.config == 2:
         I, Q, expected = synth_batch_gpu(nseg, 1234 + rank, dev, 1, args.snr, args.snr, 1.0)
         workload = ("configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr))
-    else:
+    elif args.config == 3:
         I, Q, expected = synth_batch_gpu(nseg, 4321 + rank, dev, 10, -10.0, -28.0, 0.3)
         workload = "configs[2]: %d segments per GPU x 10 overlapping signals, SNR -10..-28 dB, deep search on" % nseg
+    else:
+        raw, expected = synth_raw_gpu(nseg, 777 + rank, dev, args.snr)
+        stride = int(w.lib().wspr_iq_stride())
+        I = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
+        Q = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
+        workload = ("configs[4]: %d raw segments per step (2.4 Msps u8 IQ, 576 MB each, resident in HBM) through the "
+                    "on-GPU decimator (K0) and the decoder; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's "
+                    "4096 segments = %d such resident waves" % (nseg, args.snr, 4096 // nseg))
     torch.cuda.synchronize()
 
     opt = w.default_options()
@@ -168,7 +224,12 @@ def main():
     rec = C.sizeof(w.decoder_results)
 
     def step():
-        dec.decode(I, Q)
+        if args.config == 5:
+            rc = w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 1)
+            assert rc == 0
+            dec.decode_ptr(I.data_ptr(), Q.data_ptr(), NS, I.stride(0))
+        else:
+            dec.decode(I, Q)
         if use_dist:
             return wd.gather_spots(wd.pack_spots(dec.out, dec.nres, nseg, dec.max_results, rec), dst=0)
         return None
@@ -216,8 +277,15 @@ def main():
                                    "bytes_per_launch": STAGE_BYTES * nseg,
                                    "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
                                    "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if args.config == 5:
+            kms = (C.c_double * 1)()
+            w.lib().wspr_bench_decimate(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 3, C.addressof(kms))
+            k0_bytes = (RAW_BYTES + 360000) * nseg
+            roof["front_end_K0"] = {"bound": "hbm", "avg_launch_ms": kms[0], "bytes_per_launch": k0_bytes,
+                                    "achieved_GBs": k0_bytes / (kms[0] * 1e-3) / 1e9,
+                                    "frac": k0_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config != 5:
             cnt = min(nseg, 512)
             Ih, Qh = I[:cnt].cpu().numpy(), Q[:cnt].cpu().numpy()
             cpu, cpu_msgs = cpu_baseline(Ih, Qh, expected[:cnt], 25.0 if args.config == 2 else 60.0)

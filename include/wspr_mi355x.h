@@ -124,6 +124,10 @@ int wspr_last_timings(double *ms, int capacity);
  * data with HIP events; returns average ms per launch of each kernel in ms[0..2]. */
 int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
                         size_t seg_stride, int iters, double *ms);
+/* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
+ * ms[0] = average milliseconds per launch. */
+int wspr_bench_decimate(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_idat, void *d_qdat,
+                        int iters, double *ms);
 /* PMC calibration: `iters` launches of a 4-byte-per-lane stream copy of nfloats floats on the
  * library's stream (known traffic: 4*nfloats bytes read and written per launch). */
 int wspr_calib_copy(const void *d_src, void *d_dst, size_t nfloats, int iters);

@@ -161,6 +161,13 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
 }
 
+int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat, int iters,
+                        double* ms) {
+    try {
+        return Context::get().bench_decimate(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, iters, ms);
+    } catch (const std::exception& e) { return fail("wspr_bench_decimate", e); }
+}
+
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {
     try {

@@ -42,6 +42,7 @@ public:
                       float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, float* sync,
                       int mode);
     void subtract_single(float* id, float* qd, long np, float f0, int shift, float drift, const unsigned char* sym);
+    int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);
     int decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
                         int* h_nout);
 

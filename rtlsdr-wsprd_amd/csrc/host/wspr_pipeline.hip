@@ -724,6 +724,32 @@ int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
     return 3;
 }
 
+// average duration of the whole front end (K0 a/b/c + normalise) over `iters` launches
+int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters,
+                            double* ms) {
+    Impl& c = *d;
+    const size_t nblocks = bytes_per_seg / 2 / 6401;
+    if (nblocks == 0) return -1;
+    int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
+    int* d_nv = static_cast<int*>(c.nvalid.need((size_t)nseg * 4));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, c.stream));
+    for (int it = 0; it < iters; ++it) {
+        launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream);
+        launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
+    }
+    HIP_OK(hipEventRecord(e1, c.stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float t = 0;
+    HIP_OK(hipEventElapsedTime(&t, e0, e1));
+    ms[0] = t / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 1;
+}
+
 // ------------------------------------------------------- single-call stages --
 void Context::demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin,
                            int ifmax, float fstep, int* shift, int lagmin, int lagmax, int lagstep,

@@ -13,10 +13,11 @@
 // because int32 wrap-around arithmetic is associative.  The mixer is the
 // reference's in-place int8 trick: multiply sample n by (1, j, -1, -j)[n & 3]
 // with int8 negation (-(-128) stays -128).
-//   pass A (HBM-bound): block sums, one workgroup per PAIR of blocks so that
-//                       every 4-byte load is aligned (2R samples = 25 604 B);
-//   pass B (tiny)     : serial scan of 45 000 block sums per segment + both combs;
-//   pass C (tiny)     : 33-tap compensation FIR, taps summed in reference order.
+//   pass A (HBM-bound): block sums, one workgroup per pair of blocks, aligned 16-byte loads;
+//   pass B (tiny)     : the two integrators as parallel prefix sums over the 45 000 block sums;
+//   pass C (tiny)     : both combs + 33-tap compensation FIR, taps summed in reference order.
+// Requirement: every segment row starts 16-byte aligned (bytes_per_seg % 16 == 0) and the buffer
+// is readable up to the next multiple of 16 bytes.
 #include "wspr_device.h"
 
 #pragma clang fp contract(off)
@@ -44,47 +45,51 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 // sums[seg][block][4] = {S_I, S_Q, W_I, W_Q}
+// One workgroup per pair of blocks.  The stream is read as aligned 16-byte vectors (8 complex
+// samples); a vector starts at a sample index that is a multiple of 8, so the mixer phase of its
+// k-th sample is the compile-time constant k & 3.  Samples of a vector that belong to a
+// neighbouring pair (the pair boundaries are not 16-byte aligned) are masked out.
 __global__ __launch_bounds__(256)
 void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks,
                            int32_t* __restrict__ sums) {
     __shared__ unsigned red[4][8];
     const int seg = blockIdx.y, pair = blockIdx.x, tid = threadIdx.x;
     const int blkA = 2 * pair;
-    const uint32_t* __restrict__ words =
-        reinterpret_cast<const uint32_t*>(raw + (size_t)seg * bytes_per_seg + (size_t)pair * 2 * kR * 2);
     const bool haveB = (blkA + 1) < nblocks;
-    const int nsamp = haveB ? 2 * kR : kR;                // samples owned by this workgroup
-    const unsigned phase0 = (unsigned)((2 * pair) & 3);   // (2R*pair) mod 4, R odd
+    const long first = (long)pair * 2 * kR;                       // first sample of this pair
+    const long last = first + (haveB ? 2 * kR : kR);              // one past its last sample
+    const long seg_samples = (long)(bytes_per_seg / 2);
+    const uint4* __restrict__ vec = reinterpret_cast<const uint4*>(raw + (size_t)seg * bytes_per_seg);
+    const long v_lo = first >> 3, v_hi = (last + 7) >> 3;         // vectors touching [first, last)
+    const long v_max = (seg_samples + 7) >> 3;
 
     // all sums are modulo 2^32 (the reference's int32 integrators wrap): unsigned math
-    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // A: SI SQ WI WQ, B: SI SQ WI WQ
-    const int nwords = (nsamp + 1) / 2;
-    const size_t seg_samples = bytes_per_seg / 2;
-    const size_t pair_first = (size_t)pair * 2 * kR;
-    for (int d = tid; d < nwords; d += 256) {
-        // the odd-length tail word may straddle the end of the segment: read 2 bytes there
-        const bool whole = pair_first + 2 * (size_t)d + 1 < seg_samples;
-        const uint32_t wv = whole ? words[d]
-                                  : (uint32_t)reinterpret_cast<const uint16_t*>(words)[2 * d];
+    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // A: SI SQ WI WQ, B: SI SQ WI WQ
+    for (long v = v_lo + tid; v < v_hi && v < v_max; v += 256) {
+        const uint4 q = vec[v];                                   // rows are allocated in whole vectors
+        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = 2 * d + h;
-            if (idx < nsamp) {
-                const int a = s8(wv >> (16 * h)), b = s8(wv >> (16 * h + 8));
-                int xi, xq;
-                switch ((phase0 + (unsigned)idx) & 3u) {
-                    case 0:  xi = a;        xq = b;        break;
-                    case 1:  xi = neg8(b);  xq = a;        break;
-                    case 2:  xi = neg8(a);  xq = neg8(b);  break;
-                    default: xi = b;        xq = neg8(a);  break;
-                }
-                const int inB = idx >= kR;
-                const int wgt = kR - (idx - (inB ? kR : 0));
-                acc[4 * inB + 0] += (unsigned)xi;
-                acc[4 * inB + 1] += (unsigned)xq;
-                acc[4 * inB + 2] += (unsigned)wgt * (unsigned)xi;
-                acc[4 * inB + 3] += (unsigned)wgt * (unsigned)xq;
+        for (int k = 0; k < 8; ++k) {
+            const long n = 8 * v + k;                             // absolute sample index in the segment
+            const unsigned wv = wds[k >> 1] >> (16 * (k & 1));
+            const int a = s8(wv), b = s8(wv >> 8);
+            int xi, xq;
+            switch (k & 3) {                                      // (1, j, -1, -j)[n & 3], n = 8v + k
+                case 0:  xi = a;        xq = b;        break;
+                case 1:  xi = neg8(b);  xq = a;        break;
+                case 2:  xi = neg8(a);  xq = neg8(b);  break;
+                default: xi = b;        xq = neg8(a);  break;
             }
+            const int idx = (int)(n - first);
+            const bool inA = (n >= first) && (idx < kR) && (n < last);
+            const bool inB = (idx >= kR) && (n < last);
+            const unsigned wgt = (unsigned)(kR - (inB ? idx - kR : idx));
+            const unsigned mA = inA ? 1u : 0u, mB = inB ? 1u : 0u;
+            const unsigned ui = (unsigned)xi, uq = (unsigned)xq;
+            acc[0] += mA * ui;        acc[1] += mA * uq;
+            acc[2] += mA * wgt * ui;  acc[3] += mA * wgt * uq;
+            acc[4] += mB * ui;        acc[5] += mB * uq;
+            acc[6] += mB * wgt * ui;  acc[7] += mB * wgt * uq;
         }
     }
     const int wave = tid >> 6, lane = tid & 63;
@@ -101,28 +106,66 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
     }
 }
 
-// integrators at the decimation instants + two combs (delay 2), one thread per
-// (segment, rail); output = comb result converted to float, in place of sums
-__global__ void cic_scan_kernel(const int32_t* __restrict__ sums, int nblocks, float* __restrict__ comb) {
-    const int seg = blockIdx.x, rail = threadIdx.x;       // rail 0 = I, 1 = Q
-    if (rail > 1) return;
+// Integrators at the decimation instants by parallel prefix sums (exact: arithmetic mod 2^32 is
+// associative).  With P1 = inclusive scan of S:  I1(b) = P1[b],  I2(b) = scan_b( R*P1[b-1] + W_b ).
+// One workgroup per (segment, rail); thread t owns a contiguous chunk of blocks.
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* lds, int tid) {
+    lds[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < kScanThreads; o <<= 1) {
+        const unsigned add = (tid >= o) ? lds[tid - o] : 0u;
+        __syncthreads();
+        lds[tid] += add;
+        __syncthreads();
+    }
+    const unsigned incl = lds[tid];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads)
+void cic_scan_kernel(const int32_t* __restrict__ sums, int nblocks, uint32_t* __restrict__ x2out) {
+    __shared__ unsigned lds[kScanThreads];
+    const int seg = blockIdx.x, rail = blockIdx.y, tid = threadIdx.x;
     const int32_t* __restrict__ s = sums + (size_t)seg * nblocks * 4;
-    float* __restrict__ out = comb + ((size_t)seg * 2 + rail) * nblocks;
-    uint32_t x1 = 0, x2 = 0, c1a = 0, c1b = 0, c2a = 0, c2b = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        const uint32_t S = (uint32_t)s[4 * b + rail], W = (uint32_t)s[4 * b + 2 + rail];
-        x2 = x2 + (uint32_t)kR * x1 + W;
-        x1 = x1 + S;
-        const uint32_t y1 = x2 - c1b;  c1b = c1a;  c1a = x2;      // rtlsdr_wsprd.c:204-210
-        const uint32_t y2 = y1 - c2b;  c2b = c2a;  c2a = y1;      // :212-218
-        out[b] = (float)(int32_t)y2;
+    uint32_t* __restrict__ out = x2out + ((size_t)seg * 2 + rail) * nblocks;
+    const int per = (nblocks + kScanThreads - 1) / kScanThreads;
+    const int lo = min(nblocks, tid * per), hi = min(nblocks, lo + per);
+
+    unsigned sumS = 0;
+    for (int b = lo; b < hi; ++b) sumS += (unsigned)s[4 * b + rail];
+    const unsigned x1_start = block_exclusive_scan(sumS, lds, tid);      // I1 before block lo
+
+    unsigned x1 = x1_start, sumT = 0;
+    for (int b = lo; b < hi; ++b) {
+        sumT += (unsigned)kR * x1 + (unsigned)s[4 * b + 2 + rail];
+        x1 += (unsigned)s[4 * b + rail];
+    }
+    const unsigned x2_start = block_exclusive_scan(sumT, lds, tid);      // I2 before block lo
+
+    x1 = x1_start;
+    unsigned x2 = x2_start;
+    for (int b = lo; b < hi; ++b) {
+        x2 += (unsigned)kR * x1 + (unsigned)s[4 * b + 2 + rail];
+        x1 += (unsigned)s[4 * b + rail];
+        out[b] = x2;
     }
 }
 
-// 33-tap FIR: 32 previous comb outputs (oldest first) on taps 0..31, then the new
-// one on tap 32 (rtlsdr_wsprd.c:220-234)
+// Two combs with a two-output delay (rtlsdr_wsprd.c:204-218): y2[b] = x2[b] - 2 x2[b-2] + x2[b-4]
+// (mod 2^32, zero before the start), then the 33-tap FIR: 32 previous comb outputs (oldest first)
+// on taps 0..31 and the new one on tap 32, summed in that order (rtlsdr_wsprd.c:220-234).
+__device__ __forceinline__ float comb_out(const uint32_t* __restrict__ x2, int b) {
+    if (b < 0) return 0.0f;
+    const uint32_t c0 = x2[b], c2 = (b >= 2) ? x2[b - 2] : 0u, c4 = (b >= 4) ? x2[b - 4] : 0u;
+    const uint32_t y1 = c0 - c2, y1d = c2 - c4;       // y1[b], y1[b-2]
+    return (float)(int32_t)(y1 - y1d);
+}
+
 __global__ __launch_bounds__(256)
-void cic_fir_kernel(const float* __restrict__ comb, int nblocks, float* __restrict__ dI,
+void cic_fir_kernel(const uint32_t* __restrict__ x2all, int nblocks, float* __restrict__ dI,
                     float* __restrict__ dQ, int* __restrict__ n_out) {
     const int seg = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,15 +173,13 @@ void cic_fir_kernel(const float* __restrict__ comb, int nblocks, float* __restri
     if (m >= nblocks || m >= kMaxSamples) return;
 #pragma unroll
     for (int rail = 0; rail < 2; ++rail) {
-        const float* __restrict__ c = comb + ((size_t)seg * 2 + rail) * nblocks;
+        const uint32_t* __restrict__ x2 = x2all + ((size_t)seg * 2 + rail) * nblocks;
         float acc = 0.0f;
         for (int j = 0; j < 32; ++j) {
-            const int src = m - 32 + j;
-            const float v = (src >= 0) ? c[src] : 0.0f;
-            const float p = v * kFirTaps[j];
+            const float p = comb_out(x2, m - 32 + j) * kFirTaps[j];
             acc += p;
         }
-        const float p = c[m] * kFirTaps[32];
+        const float p = comb_out(x2, m) * kFirTaps[32];
         acc += p;
         (rail == 0 ? dI : dQ)[(size_t)seg * kIqStride + m] = acc;
     }
@@ -153,11 +194,11 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     const int nblocks = (int)(nsamp / kR);
     if (nblocks <= 0) return;
     int32_t* sums = scratch;
-    float* comb = reinterpret_cast<float*>(scratch + (size_t)nseg * nblocks * 4);
+    uint32_t* x2 = reinterpret_cast<uint32_t*>(scratch + (size_t)nseg * nblocks * 4);
     hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
                        bytes_per_seg, nblocks, sums);
-    hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg), dim3(64), 0, st, sums, nblocks, comb);
-    hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, comb, nblocks,
+    hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg, 2), dim3(kScanThreads), 0, st, sums, nblocks, x2);
+    hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, x2, nblocks,
                        dI, dQ, n_out);
 }
 
