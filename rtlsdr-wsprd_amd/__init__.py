@@ -183,5 +183,5 @@ def last_timings():
     ms = (C.c_double * 12)()
     n = lib().wspr_last_timings(C.addressof(ms), 12)
     names = ["fft_sync_ms", "host_bookkeeping_ms", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms",
-             "fano_calls", "fano_timeouts", "fano_cycles"]
+             "fano_calls", "fano_timeouts", "fano_cycles", "candidates_refined", "gpu_waves"]
     return {names[i]: ms[i] for i in range(n)}

@@ -428,20 +428,27 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
 
         const bool lockstep = opt.subtraction && ipass == 0;
         std::vector<char> stopped(nseg, 0);
-        int max_npk = 0;
-        for (int s : active) max_npk = std::max(max_npk, std::min(npk[s], kMaxCand));
+        // Speculative windows (lockstep passes): a candidate only invalidates the ones after it when
+        // it decodes AND is subtracted.  Each segment therefore submits a window of `win` consecutive
+        // candidates per wave; the window is cut at the first subtraction (later results are dropped
+        // and recomputed on the new residual) and doubles, up to 8, after a window with none.
+        std::vector<int> next_cand(nseg, 0), win(nseg, 1);
 
-        for (int rank = 0; rank < (lockstep ? max_npk : 1); ++rank) {
+        for (;;) {
             // ---- build the wave ------------------------------------------------
             std::vector<WaveItem> wave;
             for (int s : active) {
                 if (stopped[s]) continue;
                 const int n = std::min(npk[s], kMaxCand);
-                if (lockstep) { if (rank < n) wave.push_back(WaveItem{s, rank}); }
-                else for (int j = 0; j < n; ++j) wave.push_back(WaveItem{s, j});
+                const int lo = next_cand[s];
+                const int hi = lockstep ? std::min(n, lo + win[s]) : n;
+                for (int j = lo; j < hi; ++j) wave.push_back(WaveItem{s, j});
+                if (!lockstep) next_cand[s] = n;
             }
             const int nw = (int)wave.size();
-            if (nw == 0) { if (lockstep) continue; else break; }
+            if (nw == 0) break;
+            c.t_ms[10] += nw;
+            c.t_ms[11] += 1;
 
             // ---- GPU: fine sync (mode 0, mode 1) and first soft-symbol attempt ---
             FineState* h_items = static_cast<FineState*>(c.h_items.need((size_t)nw * sizeof(FineState)));
@@ -598,10 +605,13 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
             std::vector<SubJob> job_of(nw);
             std::vector<char> has_job(nw, 0);
             c.pool->run(ngroups, [&](int g) {
-              for (int i = group_start[g]; i < group_start[g + 1]; ++i) {
+              const int sg = wave[group_start[g]].seg;
+              bool cut = false;
+              for (int i = group_start[g]; i < group_start[g + 1] && !cut; ++i) {
                 WaveItem& w = wave[i];
                 const int s = w.seg;
-                if (stopped[s]) continue;
+                if (stopped[s]) break;
+                if (lockstep) next_cand[s] = w.cand + 1;
                 DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
                 cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
                 if (!(w.worth && w.decoded)) continue;
@@ -618,6 +628,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                         jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
                         job_of[i] = jb;
                         has_job[i] = 1;
+                        cut = true;            // the IQ changes: later candidates of this window are redone
                     } else {
                         stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
                         continue;
@@ -649,6 +660,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
                 }
               }
+              if (lockstep) win[sg] = cut ? 1 : std::min(8, 2 * win[sg]);
             });
             std::vector<SubJob> jobs;
             for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);
@@ -689,7 +701,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 10);
+    const int n = std::min(cap, 12);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }
