@@ -96,6 +96,17 @@ int wspr_decimate_u8_batch_device(const void *d_raw, size_t bytes_per_seg, int n
                                   void *d_idat, void *d_qdat, int normalise);
 size_t wspr_iq_stride(void);        /* floats per segment row of device IQ buffers */
 
+/* ---- recorded files and the playback print format ----------- */
+/* Replaces readRawIQfile(), reference rtlsdr_wsprd.c:555-592 (.iq: interleaved f32, Q negated,
+ * normalised to peak 0.5).  I/Q: 45000 floats each.  Returns complex samples read, 0 on error. */
+int wspr_read_iq_file(const char *filename, float *I, float *Q);
+/* Replaces readC2file(), reference rtlsdr_wsprd.c:620-667 (14-byte name, int, double dial Hz). */
+int wspr_read_c2_file(const char *filename, float *I, float *Q, double *dial_hz);
+/* Replaces writeRawIQfile(), reference rtlsdr_wsprd.c:595-617. */
+int wspr_write_iq_file(const char *filename, const float *I, const float *Q);
+/* The "Spot : ..." line of decodeRecordedFile(), reference rtlsdr_wsprd.c:691-701. */
+int wspr_format_spot(const struct decoder_results *r, char *out, size_t cap);
+
 /* ---- kernel-level entry points (parity tests and profiling) --------------- */
 /* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed). */
 void sync_and_demodulate(float *id, float *qd, long np, unsigned char *symbols, float *freq,

@@ -1,4 +1,5 @@
 // C ABI of libwspr_mi355x.so (declared in include/wspr_mi355x.h).
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -193,6 +194,77 @@ int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint3
         if (n_out) *n_out = (uint32_t)nout;
         return 0;
     } catch (const std::exception& e) { return fail("wspr_decimate_u8", e); }
+}
+
+// ---- recorded-file formats ----------------------------------------
+namespace {
+// max-abs normalisation to 0.5 of the first n samples, as every reader of the reference does
+// (rtlsdr_wsprd.c:574-589, :649-664)
+void normalise_host(float* I, float* Q, int n) {
+    float peak = 1e-24f;
+    for (int i = 0; i < n; ++i) {
+        const float a = fabsf(I[i]), b = fabsf(Q[i]);
+        if (a > peak) peak = a;
+        if (b > peak) peak = b;
+    }
+    const float scale = (float)(0.5 / (double)peak);
+    for (int i = 0; i < n; ++i) { I[i] *= scale; Q[i] *= scale; }
+}
+int load_interleaved(FILE* fd, float* I, float* Q) {
+    std::vector<float> buf(2 * (size_t)wspr::kMaxSamples);
+    const int nread = (int)fread(buf.data(), sizeof(float), buf.size(), fd);
+    const int n = nread / 2;
+    for (int i = 0; i < n; ++i) { I[i] = buf[2 * i]; Q[i] = -buf[2 * i + 1]; }   // Q sign: wsprsim convention
+    normalise_host(I, Q, n);
+    return n;
+}
+}  // namespace
+
+// readRawIQfile(), rtlsdr_wsprd.c:555-592: interleaved float32 I/Q, Q negated, normalised.
+// I/Q must hold 45000 floats; returns the number of complex samples read (0 on error).
+int wspr_read_iq_file(const char* filename, float* I, float* Q) {
+    FILE* fd = fopen(filename, "rb");
+    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
+    const int n = load_interleaved(fd, I, Q);
+    fclose(fd);
+    return n;
+}
+
+// readC2file(), rtlsdr_wsprd.c:620-667: 14-byte name, int type, double dial frequency, then the
+// same interleaved payload.  *dial_hz receives the header frequency (the reference stores it in
+// rx_options.dialfreq, :637).
+int wspr_read_c2_file(const char* filename, float* I, float* Q, double* dial_hz) {
+    FILE* fd = fopen(filename, "rb");
+    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
+    char name[15];
+    int type = 0;
+    double frequency = 0.0;
+    size_t got = fread(name, sizeof(char), 14, fd);
+    got += fread(&type, sizeof(int), 1, fd);
+    got += fread(&frequency, sizeof(double), 1, fd);
+    (void)got;
+    if (dial_hz) *dial_hz = frequency;
+    const int n = load_interleaved(fd, I, Q);
+    fclose(fd);
+    return n;
+}
+
+// writeRawIQfile(), rtlsdr_wsprd.c:595-617: always 45000 complex samples, Q negated.
+int wspr_write_iq_file(const char* filename, const float* I, const float* Q) {
+    FILE* fd = fopen(filename, "wb");
+    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
+    std::vector<float> buf(2 * (size_t)wspr::kMaxSamples);
+    for (int i = 0; i < wspr::kMaxSamples; ++i) { buf[2 * i] = I[i]; buf[2 * i + 1] = -Q[i]; }
+    const size_t nw = fwrite(buf.data(), sizeof(float), buf.size(), fd);
+    fclose(fd);
+    if (nw != buf.size()) { fprintf(stderr, "Cannot write all the data!\n"); return 0; }
+    return wspr::kMaxSamples;
+}
+
+// The -r playback spot line, rtlsdr_wsprd.c:691-701 (without the trailing newline).
+int wspr_format_spot(const struct decoder_results* r, char* out, size_t cap) {
+    return snprintf(out, cap, "Spot : %6.2f %6.2f %10.6f %2d %7s %6s %2s", r->snr, r->dt, r->freq, (int)r->drift,
+                    r->call, r->loc, r->pwr);
 }
 
 // ---- message layer under the reference's names ---------------------------------

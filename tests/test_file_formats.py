@@ -1,0 +1,60 @@
+"""recorded-file readers/writer and the playback spot line of the C ABI
+(host code, no GPU) against the oracle's reader semantics and the reference's documented output."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+import oracle_lib as ol
+import rtlsdr_wsprd_amd as w
+
+REF_IQ = os.path.join(ol.GOLDEN, "refSignalSnr0dB.iq")
+
+
+def test_iq_reader_equals_oracle_reader():
+    L = w.lib()
+    I = np.zeros(45000, np.float32); Q = np.zeros(45000, np.float32)
+    n = L.wspr_read_iq_file(REF_IQ.encode(), ol.ptr(I), ol.ptr(Q))
+    oi, oq, on = ol.read_iq_file(REF_IQ)
+    assert n == on == 45000
+    assert np.array_equal(I, oi) and np.array_equal(Q, oq)
+    assert max(np.abs(I).max(), np.abs(Q).max()) == np.float32(0.5)
+    assert L.wspr_read_iq_file(b"/nonexistent/file.iq", ol.ptr(I), ol.ptr(Q)) == 0
+
+
+def test_iq_write_read_roundtrip_and_c2(tmp_path):
+    L = w.lib()
+    rng = np.random.default_rng(2)
+    I = rng.normal(0, 0.1, 45000).astype(np.float32); Q = rng.normal(0, 0.1, 45000).astype(np.float32)
+    p = str(tmp_path / "x.iq").encode()
+    assert L.wspr_write_iq_file(p, ol.ptr(I), ol.ptr(Q)) == 45000
+    raw = np.fromfile(p.decode(), np.float32)
+    assert raw.size == 90000 and np.array_equal(raw[0::2], I) and np.array_equal(raw[1::2], -Q)   # Q negated on disk
+    I2 = np.zeros(45000, np.float32); Q2 = np.zeros(45000, np.float32)
+    assert L.wspr_read_iq_file(p, ol.ptr(I2), ol.ptr(Q2)) == 45000
+    scale = np.float32(0.5 / float(max(np.abs(I).max(), np.abs(Q).max())))
+    assert np.array_equal(I2, I * scale) and np.array_equal(Q2, Q * scale)
+    # .c2: 14-byte name + int + double + payload (rtlsdr_wsprd.c:634-640); short record
+    c2 = tmp_path / "x.c2"
+    with open(c2, "wb") as f:
+        f.write(b"150426_0918.c2")
+        f.write(struct.pack("<i", 2))
+        f.write(struct.pack("<d", 14095600.0))
+        raw[:80000].tofile(f)
+    dial = C.c_double()
+    I3 = np.zeros(45000, np.float32); Q3 = np.zeros(45000, np.float32)
+    L.wspr_read_c2_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.wspr_read_c2_file(str(c2).encode(), ol.ptr(I3), ol.ptr(Q3), C.byref(dial)) == 40000
+    assert dial.value == 14095600.0
+    sc = np.float32(0.5 / float(max(np.abs(I[:40000]).max(), np.abs(Q[:40000]).max())))
+    assert np.array_equal(I3[:40000], I[:40000] * sc) and not I3[40000:].any()
+
+
+def test_spot_line_format_matches_reference_report():
+    L = w.lib()
+    r = w.decoder_results(freq=144.490550005, sync=0.9, snr=-0.0706653595, dt=0.00533333328, drift=0.0,
+                          jitter=0, message=b"K1JT FN20 20", call=b"K1JT", loc=b"FN20", pwr=b"20", cycles=82)
+    buf = C.create_string_buffer(128)
+    L.wspr_format_spot(C.byref(r), buf, 128)
+    assert buf.value.decode() == "Spot :  -0.07   0.01 144.490550  0    K1JT   FN20 20"    # REPORT.md:202

@@ -1,0 +1,107 @@
+"""GPU tests at BASELINE.json sizes, through size-independent properties plus oracle spot checks:
+  * config 2 (1024 segments): no false decodes, batch == split batches == permuted batch
+    (segments are independent), exact agreement with the oracle on a sample,
+    residual IQ no longer contains the decoded signal;
+  * front end: batched device decimator == oracle on every row."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NS = 45000
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import rtlsdr_wsprd_amd as w
+    assert w.lib().wspr_device_ready() == 1
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    return torch, bench, w, dev
+
+
+def _tup(s):
+    return (s.message, s.call, s.loc, s.pwr, s.cycles, s.jitter, s.drift, s.sync, s.snr, s.dt, s.freq)
+
+
+def test_config2_1024_segments_properties(env):
+    torch, bench, w, dev = env
+    nseg = 1024
+    I, Q, expected = bench.synth_batch_gpu(nseg, 2024, dev, 1, -20.0, -20.0, 1.0)
+    dec = w.BatchDecoder(nseg, 16)
+    dec.decode(I, Q)
+    full = [[_tup(x) for x in dec.spots(s)] for s in range(nseg)]
+    msgs = [[t[0].decode() for t in seg] for seg in full]
+    assert sum(expected[s][0] in msgs[s] for s in range(nseg)) >= 0.95 * nseg
+    assert all(m in expected[s] for s in range(nseg) for m in msgs[s])            # no false decode
+    # independence of segments: two halves, and a permutation, give the same spots
+    h = w.BatchDecoder(nseg // 2, 16)
+    h.decode(I[: nseg // 2].contiguous(), Q[: nseg // 2].contiguous())
+    assert [[_tup(x) for x in h.spots(s)] for s in range(nseg // 2)] == full[: nseg // 2]
+    perm = torch.randperm(nseg, device=dev)
+    p = w.BatchDecoder(nseg, 16)
+    p.decode(I[perm].contiguous(), Q[perm].contiguous())
+    pl = perm.cpu().numpy()
+    assert all([_tup(x) for x in p.spots(i)] == full[pl[i]] for i in range(nseg))
+    # exact agreement with the CPU oracle on a sample
+    for s in range(0, nseg, 73):
+        ref, _, _ = ol.decode(I[s].cpu().numpy(), Q[s].cpu().numpy(), NS)
+        got = full[s]
+        assert [t[:8] + t[9:] for t in got] == [_tup(x)[:8] + _tup(x)[9:] for x in ref]
+        assert all(abs(a[8] - _tup(b)[8]) < 1e-4 for a, b in zip(got, ref))
+
+
+def test_residual_no_longer_decodes(env):
+    torch, bench, w, dev = env
+    I, Q, expected = bench.synth_batch_gpu(64, 5, dev, 1, -15.0, -15.0, 0.5)
+    Ih, Qh = I.cpu().numpy().copy(), Q.cpu().numpy().copy()
+    out = (w.decoder_results * (64 * 8))(); n = (C.c_int * 64)()
+    rc = w.lib().wspr_decode_batch(ol.ptr(Ih), ol.ptr(Qh), 64, NS, NS, w.default_options(), C.addressof(out), 8,
+                                   C.addressof(n), 1)                             # writeback = residual
+    assert rc == 0 and sum(n) >= 60
+    again = w.wspr_decode_batch(Ih, Qh, w.default_options())
+    first = [[out[s * 8 + k].message for k in range(n[s])] for s in range(64)]
+    removed = sum(1 for s in range(64) for m in first[s] if m not in [x.message for x in again[s]])
+    assert removed >= 0.9 * sum(n)          # subtraction took the decoded signals out
+
+
+def test_batched_device_decimator_equals_oracle(env):
+    torch, bench, w, dev = env
+    rng = np.random.default_rng(3)
+    nseg, nsamp = 3, 6401 * 1200 + 4800                      # bytes per row divisible by 16
+    rows = []
+    for s in range(nseg):
+        n = np.arange(nsamp)
+        sig = (3.0 + 4.0 * s) * np.exp(2j * np.pi * (-600000.0 + 25.0 * (s - 1)) / 2.4e6 * n)
+        raw = np.empty(2 * nsamp, np.uint8)
+        raw[0::2] = np.clip(np.round(127.5 + sig.real + rng.normal(0, 12, nsamp)), 0, 255).astype(np.uint8)
+        raw[1::2] = np.clip(np.round(127.5 + sig.imag + rng.normal(0, 12, nsamp)), 0, 255).astype(np.uint8)
+        rows.append(raw)
+    assert (2 * nsamp) % 16 == 0
+    d_raw = torch.from_numpy(np.stack(rows)).to(dev)
+    stride = int(w.lib().wspr_iq_stride())
+    dI = torch.zeros(nseg, stride, device=dev); dQ = torch.zeros(nseg, stride, device=dev)
+    for norm in (0, 1):
+        assert w.lib().wspr_decimate_u8_batch_device(d_raw.data_ptr(), 2 * nsamp, nseg, dI.data_ptr(), dQ.data_ptr(), norm) == 0
+        gi, gq = dI.cpu().numpy(), dQ.cpu().numpy()
+        L = ol.lib()
+        for s in range(nseg):
+            st = L.orc_decim_new()
+            oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+            fill = L.orc_decim_feed(C.c_void_p(st), ol.ptr(rows[s]), 2 * nsamp, ol.ptr(oi), ol.ptr(oq), 0, NS)
+            L.orc_decim_free(C.c_void_p(st))
+            assert fill == 1200
+            if norm:
+                L.orc_normalise(ol.ptr(oi), ol.ptr(oq), C.c_int(fill), C.c_int(NS))
+                assert np.array_equal(gi[s, :NS], oi) and np.array_equal(gq[s, :NS], oq)
+            else:
+                assert np.array_equal(gi[s, :fill], oi[:fill]) and np.array_equal(gq[s, :fill], oq[:fill])
