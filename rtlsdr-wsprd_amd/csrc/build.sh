@@ -4,6 +4,7 @@
 # sums evaluated in the reference's order (x86-64 SSE, no FMA); contraction would
 # change them.  sqrt/div stay correctly rounded (hipcc default).
 set -euo pipefail
+trap "echo BUILD FAILED >&2" ERR
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libwspr_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"

@@ -3,6 +3,9 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "wspr_message.h"
@@ -20,6 +23,44 @@ int fail(const char* where, const std::exception& e) {
 }
 }  // namespace
 
+namespace {
+// Splits a batch over the pipelines (slots).  Segments are independent, so every slot decodes a
+// contiguous share on its own stream while the others are in their host phases.
+template <class Load>
+int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
+                 int* n_results, Load load, bool writeback, float* idat, float* qdat, size_t seg_stride) {
+    const int nslots = (nseg >= 128) ? Context::slots() : 1;
+    Context& c0 = Context::get();
+    if (nslots == 1) {
+        load(c0, 0, nseg);
+        const int rc = c0.decode_resident(nseg, samples, options, decodes, max_results, n_results);
+        if (writeback) c0.store_host(idat, qdat, nseg, samples, seg_stride);
+        return rc;
+    }
+    const int dev = c0.device();
+    std::vector<std::thread> th;
+    std::vector<int> rcs(nslots, 0);
+    std::vector<std::string> errs(nslots);
+    for (int g = 0; g < nslots; ++g) {
+        const int lo = (int)((long)nseg * g / nslots), hi = (int)((long)nseg * (g + 1) / nslots);
+        th.emplace_back([&, g, lo, hi] {
+            try {
+                if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+                Context& c = Context::slot(g);
+                load(c, lo, hi - lo);
+                rcs[g] = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results,
+                                           n_results + lo);
+                if (writeback) c.store_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples, seg_stride);
+            } catch (const std::exception& e) { rcs[g] = -1; errs[g] = e.what(); }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < nslots; ++g)
+        if (rcs[g] < 0) throw std::runtime_error(errs[g].empty() ? "slot failed" : errs[g]);
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char* wspr_mi355x_version(void) { return "wspr-mi355x 0.1 (gfx950, HIP)"; }
@@ -34,12 +75,12 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
                       struct decoder_options options, struct decoder_results* decodes, int max_results,
                       int* n_results, int writeback) {
     try {
-        Context& c = Context::get();
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
-        c.load_host(idat, qdat, nseg, samples, seg_stride);
-        const int rc = c.decode_resident(nseg, samples, options, decodes, max_results, n_results);
-        if (writeback) c.store_host(idat, qdat, nseg, samples, seg_stride);
-        return rc;
+        return decode_split(nseg, samples, options, decodes, max_results, n_results,
+                            [&](Context& c, int lo, int n) {
+                                c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
+                            },
+                            writeback != 0, idat, qdat, seg_stride);
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return fail("wspr_decode_batch", e);
@@ -50,10 +91,14 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results) {
     try {
-        Context& c = Context::get();
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
-        c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
-        return c.decode_resident(nseg, samples, options, decodes, max_results, n_results);
+        const float* di = static_cast<const float*>(d_idat);
+        const float* dq = static_cast<const float*>(d_qdat);
+        return decode_split(nseg, samples, options, decodes, max_results, n_results,
+                            [&](Context& c, int lo, int n) {
+                                c.load_device(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, n, samples, seg_stride);
+                            },
+                            false, nullptr, nullptr, seg_stride);
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return fail("wspr_decode_batch_device", e);
@@ -141,7 +186,19 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
 }
 
 int wspr_last_timings(double* ms, int capacity) {
-    try { return Context::get().last_timings(ms, capacity); } catch (const std::exception& e) { return fail("wspr_last_timings", e); }
+    // times: the slowest slot (slots run concurrently); counts (index >= 7): summed over the slots
+    try {
+        double acc[16] = {0};
+        int n = 0;
+        for (int g = 0; g < Context::slots(); ++g) {
+            double t[16] = {0};
+            n = Context::slot(g).last_timings(t, 16);
+            for (int i = 0; i < n; ++i) acc[i] = (i < 7) ? (t[i] > acc[i] ? t[i] : acc[i]) : acc[i] + t[i];
+        }
+        n = n < capacity ? n : capacity;
+        for (int i = 0; i < n; ++i) ms[i] = acc[i];
+        return n;
+    } catch (const std::exception& e) { return fail("wspr_last_timings", e); }
 }
 
 int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,

@@ -12,7 +12,10 @@ namespace wspr {
 
 class Context {
 public:
-    static Context& get();          // throws std::runtime_error when no HIP device is usable
+    static Context& get();          // slot 0; throws std::runtime_error when no HIP device is usable
+    static Context& slot(int i);    // i in [0, slots())
+    static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
+    int device();
     ~Context();
 
     hipStream_t stream();
@@ -50,7 +53,7 @@ public:
     std::unique_ptr<Impl> d;
 
 private:
-    Context();
+    explicit Context(int nslots);
 };
 
 }  // namespace wspr

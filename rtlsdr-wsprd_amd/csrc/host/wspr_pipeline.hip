@@ -150,6 +150,7 @@ private:
 // ---------------------------------------------------------------- context ----
 struct Context::Impl {
     hipStream_t stream = nullptr;
+    int device = 0;
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
@@ -189,10 +190,11 @@ static void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
 }
 
-Context::Context() : d(new Impl) {
+Context::Context(int nslots) : d(new Impl) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
+    HIP_OK(hipGetDevice(&d->device));
     HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&d->ev[0]));
     HIP_OK(hipEventCreate(&d->ev[1]));
@@ -234,17 +236,36 @@ Context::Context() : d(new Impl) {
 
     int nthreads = usable_cpus();
     if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
-    nthreads = std::max(1, std::min(nthreads, 256));
+    nthreads = std::max(1, std::min(nthreads, 256) / std::max(1, nslots));   // the slots share the host's CPUs
     d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
     d->bigpool.reset(new Pool(nthreads - 1));
 }
 
 Context::~Context() {}
 
-Context& Context::get() {
-    static Context ctx;
-    return ctx;
+// Number of concurrent pipelines ("slots"): each owns a HIP stream, buffers and host pools and
+// decodes its own share of a batch, so that one slot's host phases (Fano, bookkeeping, copies)
+// overlap the other slots' kernels.
+int Context::slots() {
+    static const int n = [] {
+        int v = 3;
+        if (const char* e = getenv("WSPR_SLOTS")) v = atoi(e);
+        return std::max(1, std::min(v, 8));
+    }();
+    return n;
 }
+
+Context& Context::slot(int i) {
+    static std::mutex m;
+    static std::unique_ptr<Context> ctx[8];
+    std::lock_guard<std::mutex> g(m);
+    if (!ctx[i]) ctx[i].reset(new Context(slots()));
+    return *ctx[i];
+}
+
+Context& Context::get() { return slot(0); }
+
+int Context::device() { return d->device; }
 
 hipStream_t Context::stream() { return d->stream; }
 const DeviceTables& Context::tables() { return d->tab; }
