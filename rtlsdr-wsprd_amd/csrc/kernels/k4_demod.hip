@@ -166,6 +166,29 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
 //   demod_metric_kernel  one lane per (candidate, lag) folds the 162 symbols in order.
 // Same arithmetic per accumulator as demod_kernel => identical bits; ~8x less time
 // because loads are coalesced/LDS-served and tables are not recomputed per lag.
+// Packed-pair arithmetic: gfx950 executes v_pk_mul_f32 / v_pk_add_f32 on register pairs; each
+// half is an ordinary IEEE multiply or add (no fusion), so the per-accumulator operation
+// sequence -- and therefore every bit -- is unchanged.  Tones (0,1) and (2,3) share a pair.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct ToneAcc {
+    v2f i01, i23, q01, q23;
+    __device__ __forceinline__ void clear() { i01 = i23 = q01 = q23 = (v2f){0.0f, 0.0f}; }
+    // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c   (wsprd.c:200-207)
+    __device__ __forceinline__ void step(const float2 d, const float4 c4, const float4 s4) {
+        const v2f xx = {d.x, d.x}, yy = {d.y, d.y};
+        const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+        i01 = (i01 + xx * c01) + yy * s01;
+        i23 = (i23 + xx * c23) + yy * s23;
+        q01 = (q01 - xx * s01) + yy * c01;
+        q23 = (q23 - xx * s23) + yy * c23;
+    }
+    __device__ __forceinline__ float4 amplitudes() const {
+        const v2f e01 = i01 * i01 + q01 * q01, e23 = i23 * i23 + q23 * q23;
+        return make_float4(sqrtf(e01.x), sqrtf(e01.y), sqrtf(e23.x), sqrtf(e23.y));
+    }
+};
+
 constexpr int kTileSymsShared = 9;    // 9 x 33 lags = 297 of 320 lanes; 28 KB of LDS
 constexpr int kTileSymsOwn = 6;       // per-symbol tables: 6 x 8 KB + tile
 
@@ -214,43 +237,56 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const int pitch = (span + STEP - 1) / STEP + 1;
 
     const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)st.pad + (SHARED ? 0 : i0)) * 512;
-    for (int e = tid; e < ntab * 512; e += blockDim.x) tab[e] = gt[e];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int kbase = lag0 + kSps * i0;
-    for (int e = tid; e < span; e += blockDim.x) {
-        const int k = kbase + e;
-        const bool ok = (k > 0) && (k < np);            // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
-        tile[(e % STEP) * pitch + e / STEP] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+    const int nthr = blockDim.x;
+    // prologue: issue loads in batches of 4 so that their latencies overlap
+    for (int e0 = tid; e0 < ntab * 512; e0 += 4 * nthr) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < ntab * 512) v[u] = gt[e]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < ntab * 512) tab[e] = v[u]; }
+    }
+    for (int e0 = tid; e0 < span; e0 += 4 * nthr) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nthr, k = kbase + e;
+            const bool ok = (e < span) && (k > 0) && (k < np);   // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
+            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nthr;
+            if (e < span) tile[(e % STEP) * pitch + e / STEP] = v[u];
+        }
     }
     __syncthreads();
 
     const int il = tid / nlag, m = tid - il * nlag;
     if (il >= kTileSyms) return;
     const float4* __restrict__ tb = tab + (SHARED ? 0 : il * 512);
-    float ai[4] = {0.0f, 0.0f, 0.0f, 0.0f}, aq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int e0 = STEP * m + kSps * il;
-#pragma unroll 8
-    for (int j = 0; j < kSps; ++j) {
-        const int e = e0 + j;
-        const float2 d = tile[(e % STEP) * pitch + e / STEP];
-        const float4 c4 = tb[2 * j], s4 = tb[2 * j + 1];
-        const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
+    ToneAcc acc;
+    acc.clear();
+    if constexpr (STEP == 8 || STEP == 16) {
+        // e = STEP*m + 256*il + j with STEP | 256: row = j % STEP, column = m + (256/STEP)*il + j/STEP
+        const float2* __restrict__ col = tile + m + (kSps / STEP) * il;
+        for (int j0 = 0; j0 < kSps; j0 += STEP) {
+            const float2* __restrict__ t0 = col + j0 / STEP;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float m1 = d.x * c[t], m2 = d.y * s[t];
-            const float m3 = d.x * s[t], m4 = d.y * c[t];
-            ai[t] = (ai[t] + m1) + m2;
-            aq[t] = (aq[t] - m3) + m4;
+            for (int u = 0; u < STEP; ++u) acc.step(t0[u * pitch], tb[2 * (j0 + u)], tb[2 * (j0 + u) + 1]);
+        }
+    } else {
+        const int e0 = STEP * m + kSps * il;
+#pragma unroll 8
+        for (int j = 0; j < kSps; ++j) {
+            const int e = e0 + j;
+            acc.step(tile[(e % STEP) * pitch + e / STEP], tb[2 * j], tb[2 * j + 1]);
         }
     }
-    float p[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float e1 = ai[t] * ai[t], e2 = aq[t] * aq[t];
-        p[t] = sqrtf(e1 + e2);
-    }
-    pw_out[((size_t)item * nlag + m) * kNSymD + i0 + il] = make_float4(p[0], p[1], p[2], p[3]);
+    pw_out[((size_t)item * nlag + m) * kNSymD + i0 + il] = acc.amplitudes();
 }
 
 // folds the 162 per-symbol tone amplitudes of one (candidate, lag) in symbol order
@@ -309,7 +345,7 @@ void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restr
 // comes out of the same pass.  lane = (symbol, frequency).
 constexpr int kFreqSyms = 18;          // 18 x 5 = 90 of 128 lanes; 40 KB tables + 37 KB tile -> 2 WGs per CU
 constexpr int kNFreq = 5;
-constexpr int kFreqThreads = 128;
+constexpr int kFreqThreads = 256;     // all of them stage the tables and samples; 90 of them compute
 
 __global__ __launch_bounds__(64)
 void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin,
@@ -348,27 +384,28 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
     float2* tile = reinterpret_cast<float2*>(smem + kNFreq * 8192);        // [18][257]
     const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * 512;
     // prologue: issue the loads in batches so their latencies overlap
-    for (int e0 = 0; e0 < kNFreq * 512; e0 += kFreqThreads * 5) {
-        float4 v[5];
+    {
+        float4 v[10];                                       // 5 * 512 float4 = 10 per thread
 #pragma unroll
-        for (int u = 0; u < 5; ++u) v[u] = gt[e0 + u * kFreqThreads + tid];
+        for (int u = 0; u < 10; ++u) v[u] = gt[u * kFreqThreads + tid];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) tab[e0 + u * kFreqThreads + tid] = v[u];
+        for (int u = 0; u < 10; ++u) tab[u * kFreqThreads + tid] = v[u];
     }
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int kbase = st.shift + kSps * i0;
-    for (int e0 = 0; e0 < kFreqSyms * kSps; e0 += kFreqThreads * 6) {
-        float2 v[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int k = kbase + e0 + u * kFreqThreads + tid;
+    for (int h = 0; h < 2; ++h) {                           // 18 * 256 samples = 2 x 9 per thread
+        float2 v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int k = kbase + (h * 9 + u) * kFreqThreads + tid;
             const bool ok = (k > 0) && (k < np);
             v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int e = e0 + u * kFreqThreads + tid;
+        for (int u = 0; u < 9; ++u) {
+            const int e = (h * 9 + u) * kFreqThreads + tid;
             tile[(e >> 8) * 257 + (e & 255)] = v[u];
         }
     }
@@ -377,27 +414,11 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
     const int il = tid / kNFreq, f = tid - il * kNFreq;
     const float4* __restrict__ tb = tab + f * 512;
     const float2* __restrict__ td = tile + il * 257;
-    float ai[4] = {0.0f, 0.0f, 0.0f, 0.0f}, aq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    ToneAcc acc;
+    acc.clear();
 #pragma unroll 8
-    for (int j = 0; j < kSps; ++j) {
-        const float2 d = td[j];
-        const float4 c4 = tb[2 * j], s4 = tb[2 * j + 1];
-        const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float m1 = d.x * c[t], m2 = d.y * s[t];
-            const float m3 = d.x * s[t], m4 = d.y * c[t];
-            ai[t] = (ai[t] + m1) + m2;
-            aq[t] = (aq[t] - m3) + m4;
-        }
-    }
-    float p[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float e1 = ai[t] * ai[t], e2 = aq[t] * aq[t];
-        p[t] = sqrtf(e1 + e2);
-    }
-    pw_out[((size_t)slot * kNFreq + f) * kNSymD + i0 + il] = make_float4(p[0], p[1], p[2], p[3]);
+    for (int j = 0; j < kSps; ++j) acc.step(td[j], tb[2 * j], tb[2 * j + 1]);
+    pw_out[((size_t)slot * kNFreq + f) * kNSymD + i0 + il] = acc.amplitudes();
 }
 
 // one wave per candidate: lanes 0..4 fold one frequency hypothesis each (162 symbols in
