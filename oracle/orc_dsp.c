@@ -386,8 +386,8 @@ void orc_subtract(float *id, float *qd, long np, float f0, int shift, float drif
 }
 
 /* ----------------------------------------------------------- orchestration -- */
-/* wsprd.c:416-855.  hashtable.txt / fftw_wisdom.dat file side effects are not
- * restated (persistence is out of the hot-path scope). */
+/* wsprd.c:416-855, including the hashtable.txt persistence of :481-494 / :842-852 when
+ * options.usehashtable is set.  The fftw_wisdom.dat side effect is FFTW-specific and not restated. */
 int orc_wspr_decode(float *idat, float *qdat, int samples, orc_options opt,
                     orc_spot *spots, int *n_results, orc_trace *tr) {
     const float minsync1 = 0.10f;
@@ -403,6 +403,23 @@ int orc_wspr_decode(float *idat, float *qdat, int samples, orc_options opt,
 
     char *hashtab = (char *)calloc((size_t)ORC_HASH_N * ORC_HASH_W, 1);
     char *loctab  = (char *)calloc((size_t)ORC_HASH_N * ORC_LOC_W, 1);
+    if (opt.usehashtable) {                                   /* wsprd.c:481-494 */
+        FILE *fh = fopen("hashtable.txt", "r+");
+        if (fh) {
+            char line[80], hcall[13], hgrid[5];
+            int nh;
+            while (fgets(line, sizeof line, fh) != NULL) {
+                hgrid[0] = '\0';
+                hcall[0] = '\0';
+                if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
+                if (nh >= 0 && nh < ORC_HASH_N) {
+                    snprintf(hashtab + nh * ORC_HASH_W, ORC_HASH_W, "%s", hcall);
+                    if (strlen(hgrid) > 0) snprintf(loctab + nh * ORC_LOC_W, ORC_LOC_W, "%s", hgrid);
+                }
+            }
+            fclose(fh);
+        }
+    }
     const int blocks = orc_blocks_for(samples);
     float *ps = (float *)calloc((size_t)ORC_FFT * (blocks > 0 ? blocks : 1), sizeof(float));
     orc_cand cand[ORC_MAXCAND];
@@ -549,6 +566,15 @@ int orc_wspr_decode(float *idat, float *qdat, int samples, orc_options opt,
     }
     qsort(spots, uniques, sizeof(orc_spot), cmp_spot_snr_desc);
     *n_results = uniques;
+    if (opt.usehashtable) {                                   /* wsprd.c:842-852 */
+        FILE *fh = fopen("hashtable.txt", "w");
+        if (fh) {
+            for (int i = 0; i < ORC_HASH_N; i++)
+                if (hashtab[i * ORC_HASH_W] != '\0')
+                    fprintf(fh, "%5d %s %s\n", i, hashtab + i * ORC_HASH_W, loctab + i * ORC_LOC_W);
+            fclose(fh);
+        }
+    }
     free(ps); free(hashtab); free(loctab);
     return 0;
 }

@@ -415,6 +415,26 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     auto hashtab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg; };
     auto loctab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg + (size_t)kHashSlots * kHashWidth; };
 
+    // Callsign hash memory across calls (wsprd.c:481-494): hashtable.txt in the working directory.
+    // It makes the result depend on the order of calls, so it is honoured for single-segment calls
+    // (the daemon's one decode per two minutes) and ignored for batches (SURVEY §8e caveat, §8f3).
+    const bool persist = opt.usehashtable && nseg == 1;
+    if (persist) {
+        if (FILE* fh = fopen("hashtable.txt", "r+")) {
+            char line[80], hcall[13], hgrid[5];
+            int nh;
+            while (fgets(line, sizeof line, fh) != nullptr) {
+                hgrid[0] = hcall[0] = '\0';
+                if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
+                if (nh >= 0 && nh < kHashSlots) {
+                    snprintf(hashtab_of(0) + nh * kHashWidth, kHashWidth, "%s", hcall);
+                    if (strlen(hgrid) > 0) snprintf(loctab_of(0) + nh * kLocWidth, kLocWidth, "%s", hgrid);
+                }
+            }
+            fclose(fh);
+        }
+    }
+
     std::vector<SegBook> book(nseg);
     std::vector<int> npk;
     std::vector<DevCand> cand;
@@ -710,9 +730,19 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
         std::stable_sort(o, o + n, [](const decoder_results& a, const decoder_results& b) { return a.snr > b.snr; });
         n_results[s] = n;
         for (int slot : bk.dirty) {
+            if (persist) break;
             memset(hashtab_of(s) + (size_t)slot * kHashWidth, 0, kHashWidth);
             memset(loctab_of(s) + (size_t)slot * kLocWidth, 0, kLocWidth);
         }
+    }
+    if (persist) {                                            // wsprd.c:842-852
+        if (FILE* fh = fopen("hashtable.txt", "w")) {
+            for (int i = 0; i < kHashSlots; ++i)
+                if (hashtab_of(0)[i * kHashWidth] != '\0')
+                    fprintf(fh, "%5d %s %s\n", i, hashtab_of(0) + i * kHashWidth, loctab_of(0) + i * kLocWidth);
+            fclose(fh);
+        }
+        memset(hashtab_of(0), 0, per_seg);                   // the arena is reused by later batches
     }
     c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
     c.t_ms[7] = (double)c.n_fano.load();

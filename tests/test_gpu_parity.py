@@ -244,3 +244,64 @@ def test_decimator_bit_exact_vs_oracle(w):
     assert w.lib().wspr_decimate_u8(ol.ptr(raw), nbytes, ol.ptr(gi), ol.ptr(gq), C.byref(nout), 1) == 0
     L.orc_normalise(ol.ptr(oi), ol.ptr(oq), C.c_int(fill), C.c_int(NS))
     assert np.array_equal(gi, oi) and np.array_equal(gq, oq)
+
+
+# ------------------------------------------------------------------ message types 2 / 3, hash memory
+def _multi_segment(msgs, seed, snr=-8.0):
+    rng = np.random.default_rng(seed)
+    sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+    I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
+    for k, m in enumerate(msgs):
+        si, sq = synth.tone_signal(symf(m), -80.0 + 40.0 * k, 2.0 + 0.1 * k, 10.0 ** ((snr - 2.0 * k) / 20.0))
+        I += si; Q += sq
+    return synth.normalise(I.astype(np.float32), Q.astype(np.float32))
+
+
+def test_type2_type3_messages_equal_oracle(w):
+    """Compound callsign (type 2) and hashed callsign + 6-char grid (type 3): the type-3 spot resolves
+    <...> only because the stronger type-2 decode of the same call filled the hash memory first."""
+    I, Q = _multi_segment(["PJ4/K1ABC 37", "<PJ4/K1ABC> FK52UD 37", "K1ABC/7 30", "W1AW FN31 10"], 31)
+    spots, _, _ = w.wspr_decode(I, Q, NS)
+    ref, _, _ = ol.decode(I, Q, NS)
+    assert [_spot_tuple(x) for x in spots] == [_spot_tuple(x) for x in ref]
+    msgs = [x.message.decode() for x in spots]
+    assert "PJ4/K1ABC 37" in msgs and "<PJ4/K1ABC> FK52UD 37" in msgs and "W1AW FN31 10" in msgs
+
+
+def test_hashtable_persistence_single_segment(w, tmp_path):
+    """usehashtable = 1 (reference -H): hashtable.txt written by one call resolves a later type-3."""
+    cwd = os.getcwd()
+    try:
+        for which, d in (("gpu", tmp_path / "g"), ("cpu", tmp_path / "c")):
+            d.mkdir()
+            os.chdir(d)
+            I1, Q1 = _multi_segment(["PJ4/K1ABC 37"], 41)
+            I2, Q2 = _multi_segment(["<PJ4/K1ABC> FK52UD 37"], 42)
+            outs = []
+            for (I, Q) in ((I1, Q1), (I2, Q2)):
+                if which == "gpu":
+                    sp, _, _ = w.wspr_decode(I, Q, NS, _opt(w, 1))
+                else:
+                    sp, _, _ = ol.decode(I, Q, NS, _oopt(1))
+                outs.append([x.message.decode() for x in sp])
+            assert outs[0] == ["PJ4/K1ABC 37"] and outs[1] == ["<PJ4/K1ABC> FK52UD 37"], (which, outs)
+            txt = open("hashtable.txt").read()
+            assert "PJ4/K1ABC" in txt
+            if which == "gpu":
+                gpu_txt = txt
+            else:
+                assert txt == gpu_txt
+    finally:
+        os.chdir(cwd)
+
+
+def _opt(w, use):
+    o = w.default_options()
+    o.usehashtable = use
+    return o
+
+
+def _oopt(use):
+    o = ol.default_options()
+    o.usehashtable = use
+    return o
