@@ -26,7 +26,7 @@ done
 o="$here/obj/wspr_message.o"
 objs+=("$o")
 if [ ! -f "$o" ] || [ "$here/host/wspr_message.cpp" -nt "$o" ] || [ -n "$(find "$here/host" -name '*.h' -newer "$o" | head -1)" ]; then
-  g++ -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -c "$here/host/wspr_message.cpp" -o "$o" &
+  g++ -O3 -mpopcnt -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-format-truncation -c "$here/host/wspr_message.cpp" -o "$o" &
   pids+=($!)
 fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done

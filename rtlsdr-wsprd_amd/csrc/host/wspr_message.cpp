@@ -220,70 +220,71 @@ const FanoMetrics& default_metrics() { static const FanoMetrics m; return m; }
 
 // Fano sequential decoder (reference wsprd/fano.c:87-238; same search order,
 // threshold schedule, cycle accounting and return convention).
+//
+// The search is a serial walk of up to 810 000 steps for an undecodable vector, and such
+// time-outs dominate the host cost of crowded bands, so the walk is written for speed:
+// structure-of-arrays node storage, the encoder output of a node computed once when the node is
+// entered (both branch metrics are kept sorted), parity by popcount.
 int fano_decode(unsigned* metric, unsigned* cycles, unsigned* maxnp, unsigned char* data,
                 const unsigned char* symbols, unsigned nbits, const int mettab[2][256],
                 int delta, unsigned maxcycles) {
-    struct Node {
-        uint32_t state;     // encoder state including the hypothesised bit
-        int      gamma;     // path metric up to this node
-        int      bm[4];     // branch metrics for the 4 possible symbol pairs
-        int      ranked[2]; // best / second-best branch metric
-        int      pick;      // branch currently explored (0 = best)
-    };
     constexpr unsigned kMax = 128;
     if (nbits < 32 || nbits > kMax) return 0;
-    Node node[kMax + 1];
+    uint32_t state[kMax + 2];      // encoder state including the hypothesised bit
+    int gamma[kMax + 2];           // path metric up to the node
+    int best[kMax + 2];            // larger branch metric (tail nodes: the 0-branch metric)
+    int second[kMax + 2];          // smaller branch metric
+    unsigned char pick[kMax + 2];  // 0: exploring the better branch, 1: the other
+    int bm[kMax + 1][4];
     const int last = static_cast<int>(nbits) - 1;
     const int tail = static_cast<int>(nbits) - 31;   // the last 31 bits are forced to 0
 
     for (int k = 0; k <= last; ++k) {
-        const int s0 = symbols[2 * k], s1 = symbols[2 * k + 1];
-        node[k].bm[0] = mettab[0][s0] + mettab[0][s1];
-        node[k].bm[1] = mettab[0][s0] + mettab[1][s1];
-        node[k].bm[2] = mettab[1][s0] + mettab[0][s1];
-        node[k].bm[3] = mettab[1][s0] + mettab[1][s1];
+        const int a0 = mettab[0][symbols[2 * k]], a1 = mettab[1][symbols[2 * k]];
+        const int b0 = mettab[0][symbols[2 * k + 1]], b1 = mettab[1][symbols[2 * k + 1]];
+        bm[k][0] = a0 + b0; bm[k][1] = a0 + b1; bm[k][2] = a1 + b0; bm[k][3] = a1 + b1;
     }
-    auto rank_branches = [&](Node& nd, bool in_tail) {
-        const unsigned zero_pair = branch_pair(nd.state);
-        if (in_tail) { nd.ranked[0] = nd.bm[zero_pair]; nd.pick = 0; return; }
-        const int m0 = nd.bm[zero_pair], m1 = nd.bm[3 ^ zero_pair];
-        if (m0 > m1) { nd.ranked[0] = m0; nd.ranked[1] = m1; }
-        else         { nd.ranked[0] = m1; nd.ranked[1] = m0; nd.state |= 1u; }
-        nd.pick = 0;
+    auto enter = [&](int pos, uint32_t st) {           // rank the two branches of a fresh node
+        const unsigned zp = branch_pair(st);
+        const int m0 = bm[pos][zp];
+        if (pos >= tail) { best[pos] = m0; second[pos] = m0; state[pos] = st; pick[pos] = 0; return; }
+        const int m1 = bm[pos][3 ^ zp];
+        if (m0 > m1) { best[pos] = m0; second[pos] = m1; state[pos] = st; }
+        else         { best[pos] = m1; second[pos] = m0; state[pos] = st | 1u; }
+        pick[pos] = 0;
     };
 
     int pos = 0, deepest = 0, threshold = 0;
-    node[0].state = 0;
-    node[0].gamma = 0;
-    rank_branches(node[0], false);
+    gamma[0] = 0;
+    enter(0, 0u);
     const unsigned budget = maxcycles * nbits;
     unsigned it;
     for (it = 1; it <= budget; ++it) {
         if (pos > deepest) deepest = pos;
-        Node& cur = node[pos];
-        const int ahead = cur.gamma + cur.ranked[cur.pick];
+        const int g = gamma[pos];
+        const int ahead = g + (pick[pos] ? second[pos] : best[pos]);
         if (ahead >= threshold) {
-            if (cur.gamma < threshold + delta)
+            if (g < threshold + delta)
                 while (ahead >= threshold + delta) threshold += delta;
-            node[pos + 1].gamma = ahead;
-            node[pos + 1].state = cur.state << 1;
-            if (++pos == last + 1) break;
-            rank_branches(node[pos], pos >= tail);
+            gamma[pos + 1] = ahead;
+            const uint32_t nst = state[pos] << 1;
+            if (++pos == last + 1) { state[pos] = nst; break; }
+            enter(pos, nst);
             continue;
         }
         for (;;) {
-            if (pos == 0 || node[pos - 1].gamma < threshold) {
+            if (pos == 0 || gamma[pos - 1] < threshold) {
                 threshold -= delta;
-                if (node[pos].pick != 0) { node[pos].pick = 0; node[pos].state ^= 1u; }
+                if (pick[pos] != 0) { pick[pos] = 0; state[pos] ^= 1u; }
                 break;
             }
             --pos;
-            if (pos < tail && node[pos].pick != 1) { node[pos].pick++; node[pos].state ^= 1u; break; }
+            if (pos < tail && pick[pos] != 1) { pick[pos] = 1; state[pos] ^= 1u; break; }
         }
     }
     *maxnp = static_cast<unsigned>(deepest);
-    *metric = static_cast<unsigned>(node[pos].gamma);
-    for (unsigned k = 0; k < (nbits >> 3); ++k) data[k] = static_cast<unsigned char>(node[7 + 8 * k].state);
+    *metric = static_cast<unsigned>(gamma[pos]);
+    for (unsigned k = 0; k < (nbits >> 3); ++k) data[k] = static_cast<unsigned char>(state[7 + 8 * k]);
     *cycles = it + 1;
     return it >= budget ? -1 : 0;
 }
