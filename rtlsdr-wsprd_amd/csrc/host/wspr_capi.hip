@@ -13,6 +13,12 @@
 
 using wspr::Context;
 
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr ": ") + hipGetErrorString(e_)); \
+    } while (0)
+
 namespace {
 // The reference reports nothing but "zero spots" on failure (wsprd.c:854 returns 0
 // always).  A missing GPU is a deployment error, not a weak-signal condition: say so
@@ -141,7 +147,7 @@ int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samp
         float* ps = c.ps_buffer(nseg);
         wspr::launch_fft_bank(c.work_i(nseg), c.work_q(nseg), nullptr, nseg, samples, ps, c.tables(), c.stream());
         std::vector<float> h((size_t)nseg * wspr::kMaxBlocks * wspr::kPsStride);
-        if (hipMemcpyAsync(h.data(), ps, h.size() * 4, hipMemcpyDeviceToHost, c.stream()) != hipSuccess) return -1;
+        HIP_TRY(hipMemcpyAsync(h.data(), ps, h.size() * 4, hipMemcpyDeviceToHost, c.stream()));
         c.sync();
         memset(ps_out, 0, (size_t)nseg * wspr::kFftSize * blocks * sizeof(float));
         for (int s = 0; s < nseg; ++s)
@@ -160,16 +166,16 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
         Context& c = Context::get();
         c.load_host(idat, qdat, nseg, samples, seg_stride);
         float *d_noise = nullptr, *d_sm = nullptr;
-        if (hipMalloc(&d_noise, (size_t)nseg * 4) != hipSuccess) return -1;
-        if (hipMalloc(&d_sm, (size_t)nseg * wspr::kSmooth * 4) != hipSuccess) return -1;
+        HIP_TRY(hipMalloc(&d_noise, (size_t)nseg * 4));
+        HIP_TRY(hipMalloc(&d_sm, (size_t)nseg * wspr::kSmooth * 4));
         c.run_fft_sync(nseg, samples, maxdrift, coarse != 0, nullptr, nseg, d_noise, d_sm);
         std::vector<int> npk;
         std::vector<wspr::DevCand> cd;
         c.fetch_candidates(nseg, npk, cd);
-        if (noise_out) hipMemcpy(noise_out, d_noise, (size_t)nseg * 4, hipMemcpyDeviceToHost);
-        if (smspec_out) hipMemcpy(smspec_out, d_sm, (size_t)nseg * wspr::kSmooth * 4, hipMemcpyDeviceToHost);
-        hipFree(d_noise);
-        hipFree(d_sm);
+        if (noise_out) HIP_TRY(hipMemcpy(noise_out, d_noise, (size_t)nseg * 4, hipMemcpyDeviceToHost));
+        if (smspec_out) HIP_TRY(hipMemcpy(smspec_out, d_sm, (size_t)nseg * wspr::kSmooth * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(d_noise));
+        HIP_TRY(hipFree(d_sm));
         for (int s = 0; s < nseg; ++s) {
             npk_out[s] = npk[s];
             for (int j = 0; j < wspr::kMaxCand; ++j) {
@@ -238,16 +244,16 @@ int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint3
         Context& c = Context::get();
         nbytes &= ~(size_t)7;
         void* d_raw = nullptr;
-        if (hipMalloc(&d_raw, nbytes + 16) != hipSuccess) return -1;
-        hipMemcpy(d_raw, iq, nbytes, hipMemcpyHostToDevice);
+        HIP_TRY(hipMalloc(&d_raw, nbytes + 16));
+        HIP_TRY(hipMemcpy(d_raw, iq, nbytes, hipMemcpyHostToDevice));
         float* wi = c.work_i(1);
         float* wq = c.work_q(1);
         int nout = 0;
         const int rc = c.decimate_device(d_raw, nbytes, 1, wi, wq, normalise, &nout);
-        hipFree(d_raw);
+        HIP_TRY(hipFree(d_raw));
         if (rc) return rc;
-        hipMemcpy(I, wi, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(Q, wq, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost);
+        HIP_TRY(hipMemcpy(I, wi, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(Q, wq, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost));
         if (n_out) *n_out = (uint32_t)nout;
         return 0;
     } catch (const std::exception& e) { return fail("wspr_decimate_u8", e); }

@@ -301,7 +301,10 @@ void Context::store_host(float* I, float* Q, int nseg, int samples, size_t strid
     HIP_OK(hipMemcpy2DAsync(Q, stride * 4, d->iqQ.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
     HIP_OK(hipStreamSynchronize(d->stream));
 }
-void Context::sync() { HIP_OK(hipStreamSynchronize(d->stream)); }
+void Context::sync() {
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(d->stream));
+}
 
 float* Context::ps_buffer(int nseg) {
     return static_cast<float*>(d->ps.need((size_t)nseg * kMaxBlocks * kPsStride * 4));
@@ -353,13 +356,15 @@ struct Timer {
     hipStream_t st;
     double* acc;
     Timer(hipEvent_t a_, hipEvent_t b_, hipStream_t s, double* acc_) : a(a_), b(b_), st(s), acc(acc_) {
-        hipEventRecord(a, st);
+        HIP_OK(hipEventRecord(a, st));
     }
+    // waits for everything queued so far and surfaces launch/execution errors loudly
     void stop() {
-        hipEventRecord(b, st);
-        hipEventSynchronize(b);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(b, st));
+        HIP_OK(hipEventSynchronize(b));
         float ms = 0;
-        hipEventElapsedTime(&ms, a, b);
+        HIP_OK(hipEventElapsedTime(&ms, a, b));
         *acc += ms;
     }
 };
@@ -783,7 +788,7 @@ int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
             HIP_OK(hipEventElapsedTime(&t, ev[4 * it + k], ev[4 * it + k + 1]));
             ms[k] += t / iters;
         }
-    for (auto& e : ev) hipEventDestroy(e);
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return 3;
 }
 
@@ -808,8 +813,8 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     float t = 0;
     HIP_OK(hipEventElapsedTime(&t, e0, e1));
     ms[0] = t / iters;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 1;
 }
 

@@ -560,9 +560,10 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
         constexpr size_t lds = kNFreq * 8192 + kFreqSyms * 257 * sizeof(float2);        // 77 KB
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(freq_tile_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
+        // 77 KB of dynamic LDS needs an explicit opt-in (default limit 64 KB)
+        static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(freq_tile_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)opt_in;
         hipLaunchKernelGGL(freq_tile_kernel, dim3(kNSymD / kFreqSyms, n_shared), dim3(kFreqThreads), lds, st, dI, dQ,
                            samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
