@@ -67,10 +67,54 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
     unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // A: SI SQ WI WQ, B: SI SQ WI WQ
     for (long v = v_lo + tid; v < v_hi && v < v_max; v += 256) {
         const uint4 q = vec[v];                                   // rows are allocated in whole vectors
+        const long n0 = 8 * v;
+        const int idx0 = (int)(n0 - first);
+        const bool fullA = (idx0 >= 0) && (idx0 + 7 < kR) && (n0 + 7 < last);
+        const bool fullB = haveB && (idx0 >= kR) && (n0 + 7 < last);
+        // a raw byte 0x00 is -128 after the sign flip and its int8 negation wraps: such
+        // vectors (clipping only) and the few that straddle a block edge take the per-sample path
+        const unsigned z = ((q.x - 0x01010101u) & ~q.x) | ((q.y - 0x01010101u) & ~q.y) |
+                           ((q.z - 0x01010101u) & ~q.z) | ((q.w - 0x01010101u) & ~q.w);
+        if ((fullA || fullB) && !(z & 0x80808080u)) {
+            // Fast path, 8 samples of one block.  Sample k of the vector has mixer phase k & 3, so a
+            // dword [I_k Q_k I_k+1 Q_k+1] (k even) contributes  xi = (+I_k, -Q_k+1), xq = (+Q_k, +I_k+1)
+            // for k = 0, 4 and  xi = (-I_k, +Q_k+1), xq = (-Q_k, -I_k+1)  for k = 2, 6:
+            // signed 4 x int8 dot products with constant weights (bytes little-endian in the constant).
+            const int w0 = (int)(q.x ^ 0x80808080u), w1 = (int)(q.y ^ 0x80808080u);
+            const int w2 = (int)(q.z ^ 0x80808080u), w3 = (int)(q.w ^ 0x80808080u);
+            constexpr int kIe = (int)0xff000001u;   // (+1, 0, 0, -1): xi of phases (0,1)
+            constexpr int kIo = (int)0x010000ffu;   // (-1, 0, 0, +1): xi of phases (2,3)
+            constexpr int kQe = (int)0x00010100u;   // ( 0,+1,+1, 0): xq of phases (0,1)
+            constexpr int kQo = (int)0x00ffff00u;   // ( 0,-1,-1, 0): xq of phases (2,3)
+            int tI = __builtin_amdgcn_sdot4(w0, kIe, 0, false);
+            tI = __builtin_amdgcn_sdot4(w1, kIo, tI, false);
+            tI = __builtin_amdgcn_sdot4(w2, kIe, tI, false);
+            tI = __builtin_amdgcn_sdot4(w3, kIo, tI, false);
+            int tQ = __builtin_amdgcn_sdot4(w0, kQe, 0, false);
+            tQ = __builtin_amdgcn_sdot4(w1, kQo, tQ, false);
+            tQ = __builtin_amdgcn_sdot4(w2, kQe, tQ, false);
+            tQ = __builtin_amdgcn_sdot4(w3, kQo, tQ, false);
+            // sum_k k * x_k: weights (0,-1 | -2,+3 | +4,-5 | -6,+7) for xi, (0,+1 | -2,-3 | +4,+5 | -6,-7) for xq
+            int uI = __builtin_amdgcn_sdot4(w0, (int)0xff000000u, 0, false);
+            uI = __builtin_amdgcn_sdot4(w1, (int)0x030000feu, uI, false);
+            uI = __builtin_amdgcn_sdot4(w2, (int)0xfb000004u, uI, false);
+            uI = __builtin_amdgcn_sdot4(w3, (int)0x070000fau, uI, false);
+            int uQ = __builtin_amdgcn_sdot4(w0, (int)0x00010000u, 0, false);
+            uQ = __builtin_amdgcn_sdot4(w1, (int)0x00fdfe00u, uQ, false);
+            uQ = __builtin_amdgcn_sdot4(w2, (int)0x00050400u, uQ, false);
+            uQ = __builtin_amdgcn_sdot4(w3, (int)0x00f9fa00u, uQ, false);
+            // W += sum_k (R - off0 - k) x_k = (R - off0) * t - u
+            const int wbase = kR - (fullB ? idx0 - kR : idx0);
+            const unsigned wI = (unsigned)(__mul24(wbase, tI) - uI), wQ = (unsigned)(__mul24(wbase, tQ) - uQ);
+            const unsigned mA = fullA ? 1u : 0u, mB = fullA ? 0u : 1u;
+            acc[0] += mA * (unsigned)tI;  acc[1] += mA * (unsigned)tQ;  acc[2] += mA * wI;  acc[3] += mA * wQ;
+            acc[4] += mB * (unsigned)tI;  acc[5] += mB * (unsigned)tQ;  acc[6] += mB * wI;  acc[7] += mB * wQ;
+            continue;
+        }
         const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const long n = 8 * v + k;                             // absolute sample index in the segment
+            const long n = n0 + k;                                // absolute sample index in the segment
             const unsigned wv = wds[k >> 1] >> (16 * (k & 1));
             const int a = s8(wv), b = s8(wv >> 8);
             int xi, xq;
