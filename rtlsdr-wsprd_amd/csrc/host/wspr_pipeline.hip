@@ -477,17 +477,37 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
         // Speculative windows (lockstep passes): a candidate only invalidates the ones after it when
         // it decodes AND is subtracted.  Each segment therefore submits a window of `win` consecutive
         // candidates per wave; the window is cut at the first subtraction (later results are dropped
-        // and recomputed on the new residual) and doubles, up to 8, after a window with none.
+        // and recomputed on the new residual) and doubles, up to 64, after a window with none.
         std::vector<int> next_cand(nseg, 0), win(nseg, 1);
 
         for (;;) {
             // ---- build the wave ------------------------------------------------
+            // A refined candidate holds up to ~110 KB of scratch (tone amplitudes for 43 lags) plus
+            // its phasor tables, so the wave size is bounded: speculative windows shrink first, and
+            // whatever still does not fit waits for the next wave.
+            constexpr int kMaxWave = 65536;
+            if (lockstep) {
+                for (;;) {
+                    long total = 0;
+                    bool shrinkable = false;
+                    for (int s : active) {
+                        if (stopped[s]) continue;
+                        const int left = std::min(npk[s], kMaxCand) - next_cand[s];
+                        total += std::max(0, std::min(left, win[s]));
+                        shrinkable |= win[s] > 1;
+                    }
+                    if (total <= kMaxWave || !shrinkable) break;
+                    for (int s : active) win[s] = std::max(1, win[s] / 2);
+                }
+            }
             std::vector<WaveItem> wave;
             for (int s : active) {
                 if (stopped[s]) continue;
                 const int n = std::min(npk[s], kMaxCand);
                 const int lo = next_cand[s];
                 const int hi = lockstep ? std::min(n, lo + win[s]) : n;
+                if (hi <= lo) continue;
+                if (!wave.empty() && (int)wave.size() + (hi - lo) > kMaxWave) break;   // next wave
                 for (int j = lo; j < hi; ++j) wave.push_back(WaveItem{s, j});
                 if (!lockstep) next_cand[s] = n;
             }
@@ -706,7 +726,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
                 }
               }
-              if (lockstep) win[sg] = cut ? 1 : std::min(8, 2 * win[sg]);
+              if (lockstep) win[sg] = cut ? 1 : std::min(64, 2 * win[sg]);
             });
             std::vector<SubJob> jobs;
             for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);

@@ -170,6 +170,8 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
                         const unsigned char* __restrict__ pr3) {
     __shared__ float amp[kCoarseRows * kCoarsePitch];
     __shared__ float res[288];
+    __shared__ float best_s;
+    __shared__ int arg_s;
     const int tid = threadIdx.x;
     const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
     const float* __restrict__ P = ps + (size_t)seg * kMaxBlocks * kPsStride;
@@ -182,9 +184,23 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
         const int if0 = (int)((double)cd.freq / kHalfDf + 256.0);
         const int col0 = if0 - 6 - kPsBin0;            // first staged column
         __syncthreads();
-        for (int e = tid; e < kCoarseRows * blocks; e += blockDim.x) {
-            const int t = e / kCoarseRows, r = e - t * kCoarseRows;
-            amp[r * kCoarsePitch + t] = sqrtf(P[(size_t)t * kPsStride + col0 + r]);
+        // stage sqrt(ps) for the 11 columns this candidate can touch; loads are issued in batches
+        // of 4 so that their latencies overlap
+        const int total = kCoarseRows * blocks;
+        for (int e0 = tid; e0 < total; e0 += 4 * (int)blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                const int t = e / kCoarseRows, r = e - t * kCoarseRows;
+                v[u] = (e < total) ? P[(size_t)t * kPsStride + col0 + r] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                const int t = e / kCoarseRows, r = e - t * kCoarseRows;
+                if (e < total) amp[r * kCoarsePitch + t] = sqrtf(v[u]);
+            }
         }
         __syncthreads();
 
@@ -196,6 +212,7 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
             const int ifr = if0 - 1 + fi;
             float ss = 0.0f, pw = 0.0f;
             bool any = false;
+#pragma unroll 6
             for (int k = 0; k < kNSymD; ++k) {
                 const int low = (pat == 0 && k > 81) || (pat == 2 && k < 81);
                 const int ifd = ifr - low;
@@ -214,11 +231,26 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
             res[tid] = any ? ss / pw : __int_as_float(0x7fc00000);
         }
         __syncthreads();
-        if (tid == 0) {
+        // first hypothesis (in the reference's loop order) with the strictly largest metric:
+        // max by value, ties to the lowest index -- an order-independent reduction
+        if (tid < 64) {
             float best = -1e30f;
             int arg = -1;
-            for (int h = 0; h < nhyp; ++h)
-                if (res[h] > best) { best = res[h]; arg = h; }
+            for (int h = tid; h < nhyp; h += 64)
+                if (res[h] > best) { best = res[h]; arg = h; }       // ascending h: keeps the first
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int oa = __shfl_xor(arg, o);
+                const bool take = (oa >= 0) && (arg < 0 || ob > best || (ob == best && oa < arg));
+                if (take) { best = ob; arg = oa; }
+            }
+            if (tid == 0) { best_s = best; arg_s = arg; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float best = best_s;
+            const int arg = arg_s;
             if (arg >= 0) {
                 const int fi = arg / (32 * npat);
                 const int rem = arg - fi * 32 * npat;
