@@ -107,6 +107,15 @@ int wspr_write_iq_file(const char *filename, const float *I, const float *Q);
 /* The "Spot : ..." line of decodeRecordedFile(), reference rtlsdr_wsprd.c:691-701. */
 int wspr_format_spot(const struct decoder_results *r, char *out, size_t cap);
 
+/* The daemon's stdout line, reference printSpots() rtlsdr_wsprd.c:447-474 (UTC frame time). */
+int wspr_format_spot_timestamped(const struct decoder_results *r, int year, int month, int day, int hour,
+                                 int minute, char *out, size_t cap);
+/* Text of the wsprnet.org report URL, reference postSpots() rtlsdr_wsprd.c:390-397 (r == NULL: the
+ * "no spot" status report) and :414-429 (one spot).  Formatting only -- nothing is sent. */
+int wspr_format_wsprnet_url(const struct decoder_results *r, const struct decoder_options *opt,
+                            double dial_hz, int year, int month, int day, int hour, int minute,
+                            const char *app_version, char *out, size_t cap);
+
 /* ---- kernel-level entry points (parity tests and profiling) --------------- */
 /* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed). */
 void sync_and_demodulate(float *id, float *qd, long np, unsigned char *symbols, float *freq,

@@ -1,4 +1,5 @@
 // C ABI of libwspr_mi355x.so (declared in include/wspr_mi355x.h).
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -64,6 +65,19 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
     for (int g = 0; g < nslots; ++g)
         if (rcs[g] < 0) throw std::runtime_error(errs[g].empty() ? "slot failed" : errs[g]);
     return 0;
+}
+}  // namespace
+
+namespace {
+// RFC 3986 unreserved characters pass, everything else is %XX (what curl_easy_escape does)
+std::string url_escape(const char* s) {
+    static const char hex[] = "0123456789ABCDEF";
+    std::string o;
+    for (const unsigned char* p = reinterpret_cast<const unsigned char*>(s); *p; ++p) {
+        if (isalnum(*p) || *p == '-' || *p == '.' || *p == '_' || *p == '~') o.push_back((char)*p);
+        else { o.push_back('%'); o.push_back(hex[*p >> 4]); o.push_back(hex[*p & 15]); }
+    }
+    return o;
 }
 }  // namespace
 
@@ -328,6 +342,30 @@ int wspr_write_iq_file(const char* filename, const float* I, const float* Q) {
 int wspr_format_spot(const struct decoder_results* r, char* out, size_t cap) {
     return snprintf(out, cap, "Spot : %6.2f %6.2f %10.6f %2d %7s %6s %2s", r->snr, r->dt, r->freq, (int)r->drift,
                     r->call, r->loc, r->pwr);
+}
+
+// ---- live-receiver output formats (formatting only, no network) ------
+// printSpots(), rtlsdr_wsprd.c:447-474: the daemon's stdout line with the UTC frame time.
+int wspr_format_spot_timestamped(const struct decoder_results* r, int year, int month, int day, int hour, int minute,
+                                 char* out, size_t cap) {
+    return snprintf(out, cap, "Spot :  %04d-%02d-%02d %02d:%02dz %6.2f %6.2f %10.6f %2d %7s %6s %2s", year, month, day,
+                    hour, minute, r->snr, r->dt, r->freq, (int)r->drift, r->call, r->loc, r->pwr);
+}
+
+// The wsprnet.org report URL of postSpots(), rtlsdr_wsprd.c:414-429 (spot) and :390-397 (empty
+// report when r == NULL).  Only the text is produced; nothing is sent.
+int wspr_format_wsprnet_url(const struct decoder_results* r, const struct decoder_options* opt, double dial_hz,
+                            int year, int month, int day, int hour, int minute, const char* app_version,
+                            char* out, size_t cap) {
+    const std::string rcall = url_escape(opt->rcall), rloc = url_escape(opt->rloc);
+    if (!r)
+        return snprintf(out, cap,
+                        "https://wsprnet.org/post?function=wsprstat&rcall=%s&rgrid=%s&rqrg=%.6f&tpct=%.2f&tqrg=%.6f&dbm=%d&version=%s&mode=2",
+                        rcall.c_str(), rloc.c_str(), dial_hz / 1e6, 0.0f, dial_hz / 1e6, 0, app_version);
+    return snprintf(out, cap,
+                    "https://wsprnet.org/post?function=wspr&rcall=%s&rgrid=%s&rqrg=%.6f&date=%02d%02d%02d&time=%02d%02d&sig=%.0f&dt=%.1f&tqrg=%.6f&tcall=%s&tgrid=%s&dbm=%s&version=%s&mode=2",
+                    rcall.c_str(), rloc.c_str(), r->freq, year % 100, month, day, hour, minute, r->snr, r->dt, r->freq,
+                    r->call, r->loc, r->pwr, app_version);
 }
 
 // ---- message layer under the reference's names ---------------------------------

@@ -58,3 +58,24 @@ def test_spot_line_format_matches_reference_report():
     buf = C.create_string_buffer(128)
     L.wspr_format_spot(C.byref(r), buf, 128)
     assert buf.value.decode() == "Spot :  -0.07   0.01 144.490550  0    K1JT   FN20 20"    # REPORT.md:202
+
+
+def test_daemon_line_and_wsprnet_url_formats():
+    """rtlsdr_wsprd.c:447-474 and :390-429 (text only)."""
+    L = w.lib()
+    r = w.decoder_results(freq=14.097150, sync=0.9, snr=-21.4, dt=0.31, drift=-1.0, jitter=0,
+                          message=b"K1JT FN20 20", call=b"K1JT", loc=b"FN20", pwr=b"20", cycles=82)
+    buf = C.create_string_buffer(600)
+    L.wspr_format_spot_timestamped(C.byref(r), 2026, 9, 28, 1, 30, buf, 600)
+    assert buf.value.decode() == "Spot :  2026-09-28 01:30z -21.40   0.31  14.097150 -1    K1JT   FN20 20"
+    opt = w.default_options(freq=14095600)
+    opt.rcall = b"VA2GKA/P"
+    opt.rloc = b"FN35"
+    L.wspr_format_wsprnet_url.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_char_p, C.c_char_p, C.c_size_t]
+    L.wspr_format_wsprnet_url(C.addressof(r), C.addressof(opt), 14095600.0, 2026, 9, 28, 1, 30, b"rtlsdr-056", buf, 600)
+    assert buf.value.decode() == ("https://wsprnet.org/post?function=wspr&rcall=VA2GKA%2FP&rgrid=FN35&rqrg=14.097150&date=260928"
+                                  "&time=0130&sig=-21&dt=0.3&tqrg=14.097150&tcall=K1JT&tgrid=FN20&dbm=20&version=rtlsdr-056&mode=2")
+    L.wspr_format_wsprnet_url(None, C.addressof(opt), 14095600.0, 2026, 9, 28, 1, 30, b"rtlsdr-056", buf, 600)
+    assert buf.value.decode() == ("https://wsprnet.org/post?function=wsprstat&rcall=VA2GKA%2FP&rgrid=FN35&rqrg=14.095600&tpct=0.00"
+                                  "&tqrg=14.095600&dbm=0&version=rtlsdr-056&mode=2")
