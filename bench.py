@@ -193,7 +193,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1
+    use_dist = world > 1 or os.environ.get("WSPR_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -223,6 +223,8 @@ def main():
     dec = w.BatchDecoder(nseg, max_results=16 if args.config == 2 else 32, options=opt)
     rec = C.sizeof(w.decoder_results)
 
+    gatherer = wd.SpotGatherer(dec.out, dec.nres, nseg, dec.max_results, rec, dst=0) if use_dist else None
+
     def step():
         if args.config == 5:
             rc = w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 1)
@@ -231,7 +233,7 @@ def main():
         else:
             dec.decode(I, Q)
         if use_dist:
-            return wd.gather_spots(wd.pack_spots(dec.out, dec.nres, nseg, dec.max_results, rec), dst=0)
+            return gatherer.gather()            # spot records of every rank land on rank 0 (RCCL)
         return None
 
     def fence():
@@ -261,7 +263,7 @@ def main():
     timings = w.last_timings()
 
     if rank == 0:
-        total_spots = int(wd.unpack_counts(gathered).sum()) if gathered is not None else dec.total_spots()
+        total_spots = int(gathered[0].sum()) if gathered is not None else dec.total_spots()
         # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
         ms = (C.c_double * 3)()
         w.lib().wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20, C.addressof(ms))

@@ -60,6 +60,44 @@ def gather_spots(packed, dst=0):
     return torch.stack(bufs).cpu()
 
 
+class SpotGatherer:
+    """Per-step fan-in of spot records with preallocated buffers (no per-step allocation or host
+    concatenation): the ctypes result arrays are viewed in place, copied to the device, gathered
+    over RCCL on `dst`, and landed in pinned host memory there."""
+
+    def __init__(self, results_array, counts, nseg, max_results, record_size, dst=0):
+        self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
+        self.nccl = dist.get_backend() == "nccl"
+        dev = _dev()
+        self.rec_src = torch.from_numpy(np.frombuffer(results_array, dtype=np.uint8).reshape(nseg, max_results * record_size))
+        self.cnt_src = torch.from_numpy(np.frombuffer(counts, dtype=np.int32).reshape(nseg))
+        self.rec_dev = torch.empty_like(self.rec_src, device=dev)
+        self.cnt_dev = torch.empty_like(self.cnt_src, device=dev)
+        if self.rank == dst:
+            self.rec_all = [torch.empty_like(self.rec_dev) for _ in range(self.world)]
+            self.cnt_all = [torch.empty_like(self.cnt_dev) for _ in range(self.world)]
+            pin = self.nccl
+            self.rec_host = torch.empty((self.world,) + tuple(self.rec_src.shape), dtype=torch.uint8, pin_memory=pin)
+            self.cnt_host = torch.empty((self.world, nseg), dtype=torch.int32, pin_memory=pin)
+        else:
+            self.rec_all = self.cnt_all = None
+
+    def gather(self):
+        """Returns (counts [world, nseg] int32, records [world, nseg, K*record] uint8) on dst, else None."""
+        self.rec_dev.copy_(self.rec_src, non_blocking=True)
+        self.cnt_dev.copy_(self.cnt_src, non_blocking=True)
+        dist.gather(self.rec_dev, self.rec_all, dst=self.dst)
+        dist.gather(self.cnt_dev, self.cnt_all, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            self.rec_host[r].copy_(self.rec_all[r], non_blocking=True)
+            self.cnt_host[r].copy_(self.cnt_all[r], non_blocking=True)
+        if self.nccl:
+            torch.cuda.current_stream().synchronize()
+        return self.cnt_host, self.rec_host
+
+
 def unpack_counts(gathered):
     """[world, nseg, rec] uint8 -> int32 [world, nseg] spot counts."""
     return gathered[:, :, :4].contiguous().numpy().view(np.int32).reshape(gathered.shape[0], gathered.shape[1])

@@ -51,10 +51,13 @@ def _worker(rank, world, port, q):
     lo, hi = wd.shard_range(NSEG, rank, world)
     out, cnt, n = _decode_shard(lo, hi, segs, opt)
     g = wd.gather_spots(wd.pack_spots(out, cnt, n, K, 80), dst=0)
+    g2 = wd.SpotGatherer(out, cnt, n, K, 80, dst=0).gather()        # the preallocated path bench.py uses
     if rank == 0:
+        assert g2[0].tolist() == wd.unpack_counts(g).tolist()
+        assert bytes(g2[1].numpy().tobytes()) == bytes(g[:, :, 4:].contiguous().numpy().tobytes())
         q.put((wd.unpack_counts(g).tolist(), wd.unpack_messages(g, K, 80)))
     else:
-        assert g is None
+        assert g is None and g2 is None
     dist.barrier()
     dist.destroy_process_group()
 
