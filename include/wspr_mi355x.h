@@ -144,6 +144,17 @@ int wspr_last_timings(double *ms, int capacity);
  * data with HIP events; returns average ms per launch of each kernel in ms[0..2]. */
 int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
                         size_t seg_stride, int iters, double *ms);
+/* Device Fano search (K6) over n soft-symbol vectors of 162 bytes in transmission
+ * (interleaved) order, i.e. deinterleave() + fano() of reference wsprd.c:759-761 with delta 60.
+ * Outputs per vector: ret (0 / -1), cycles, metric, maxnp, data[10]. */
+int wspr_fano_batch_device(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
+                           unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data);
+/* Scheduler tuning (batches of >= 256 segments per slot): the host Fano pool gives every attempt
+ * `cycles_per_bit` cycles per bit (default 600, env WSPR_FANO_FAST); attempts still running then are
+ * finished by K6 with the reference's 10000, and a segment in which one of those decodes after all
+ * is decoded again with the full budget everywhere, so results never depend on this value.
+ * >= 10000 disables the split.  Returns the previous value. */
+unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
 /* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
  * ms[0] = average milliseconds per launch. */
 int wspr_bench_decimate(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_idat, void *d_qdat,

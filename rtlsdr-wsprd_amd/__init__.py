@@ -180,8 +180,9 @@ class BatchDecoder:
 
 
 def last_timings():
-    ms = (C.c_double * 12)()
-    n = lib().wspr_last_timings(C.addressof(ms), 12)
-    names = ["fft_sync_ms", "host_bookkeeping_ms", "unused2", "demod_ms", "subtract_ms", "host_fano_ms", "total_ms",
-             "fano_calls", "fano_timeouts", "fano_cycles", "candidates_refined", "gpu_waves"]
+    ms = (C.c_double * 16)()
+    n = lib().wspr_last_timings(C.addressof(ms), 16)
+    names = ["fft_sync_ms", "host_bookkeeping_ms", "device_fano_tail_ms", "demod_ms", "subtract_ms", "host_fano_ms",
+             "total_ms", "fano_calls", "fano_timeouts", "fano_cycles", "candidates_refined", "gpu_waves",
+             "fano_left_to_device", "segments_redecoded"]
     return {names[i]: ms[i] for i in range(n)}

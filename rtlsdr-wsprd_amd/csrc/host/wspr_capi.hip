@@ -33,14 +33,15 @@ int fail(const char* where, const std::exception& e) {
 namespace {
 // Splits a batch over the pipelines (slots).  Segments are independent, so every slot decodes a
 // contiguous share on its own stream while the others are in their host phases.
-template <class Load>
+template <class Load, class Reload>
 int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
-                 int* n_results, Load load, bool writeback, float* idat, float* qdat, size_t seg_stride) {
+                 int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride) {
     const int nslots = (nseg >= 128) ? Context::slots() : 1;
     Context& c0 = Context::get();
     if (nslots == 1) {
         load(c0, 0, nseg);
-        const int rc = c0.decode_resident(nseg, samples, options, decodes, max_results, n_results);
+        const int rc = c0.decode_resident(nseg, samples, options, decodes, max_results, n_results,
+                                          [&](const std::vector<int>& segs) { reload(c0, 0, segs); });
         if (writeback) c0.store_host(idat, qdat, nseg, samples, seg_stride);
         return rc;
     }
@@ -56,7 +57,7 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
                 Context& c = Context::slot(g);
                 load(c, lo, hi - lo);
                 rcs[g] = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results,
-                                           n_results + lo);
+                                           n_results + lo, [&c, &reload, lo](const std::vector<int>& segs) { reload(c, lo, segs); });
                 if (writeback) c.store_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples, seg_stride);
             } catch (const std::exception& e) { rcs[g] = -1; errs[g] = e.what(); }
         });
@@ -100,6 +101,9 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
                             [&](Context& c, int lo, int n) {
                                 c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
                             },
+                            [&](Context& c, int lo, const std::vector<int>& segs) {
+                                c.reload_rows(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, false, seg_stride, samples, segs);
+                            },
                             writeback != 0, idat, qdat, seg_stride);
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
@@ -117,6 +121,9 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
                             [&](Context& c, int lo, int n) {
                                 c.load_device(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, n, samples, seg_stride);
+                            },
+                            [&](Context& c, int lo, const std::vector<int>& segs) {
+                                c.reload_rows(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, true, seg_stride, samples, segs);
                             },
                             false, nullptr, nullptr, seg_stride);
     } catch (const std::exception& e) {
@@ -237,6 +244,17 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
         c.sync();
         return 0;
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
+}
+
+unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
+    return wspr::fano_fast_budget().exchange(cycles_per_bit);
+}
+
+int wspr_fano_batch_device(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
+                           unsigned* metric, unsigned* maxnp, unsigned char* data) {
+    try {
+        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data);
+    } catch (const std::exception& e) { return fail("wspr_fano_batch_device", e); }
 }
 
 int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat, int iters,

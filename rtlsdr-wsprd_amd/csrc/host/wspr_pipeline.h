@@ -2,6 +2,8 @@
 // call): HIP stream, constant tables, grow-only device/pinned buffers, host pool.
 #pragma once
 #include <chrono>
+#include <atomic>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -9,6 +11,16 @@
 #include "../kernels/wspr_device.h"
 
 namespace wspr {
+
+// Fano attempts the host pool left unfinished (see Context::decode_resident)
+// cycles/bit the host Fano pool spends before leaving an attempt to the device tail (K6)
+std::atomic<unsigned>& fano_fast_budget();
+
+struct PendingFano {
+    std::vector<int> seg;                 // owning segment of each attempt
+    std::vector<unsigned char> sym;       // 162 soft symbols each, transmission order
+    void add(int s, const unsigned char* v) { seg.push_back(s); sym.insert(sym.end(), v, v + 162); }
+};
 
 class Context {
 public:
@@ -28,6 +40,8 @@ public:
     void load_host(const float* I, const float* Q, int nseg, int samples, size_t stride);
     void load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride);
     void store_host(float* I, float* Q, int nseg, int samples, size_t stride);
+    void reload_rows(const float* I, const float* Q, bool device, size_t stride, int samples,
+                     const std::vector<int>& segs);
     void sync();
 
     float* ps_buffer(int nseg);
@@ -36,8 +50,13 @@ public:
     void fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand);
 
     // the decoder proper, on the working buffers
+    // reload(segs): restore the original IQ of the listed segments in the working buffers (needed
+    // for the exact re-decode after a late Fano success); empty function = no fast/tail split
     int decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
-                        int max_results, int* n_results);
+                        int max_results, int* n_results,
+                        const std::function<void(const std::vector<int>&)>& reload = nullptr);
+    int decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
+                    int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend);
     int last_timings(double* ms, int cap);
     int bench_fft_sync(int nseg, int samples, int iters, double* ms);
 
@@ -45,6 +64,8 @@ public:
                       float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, float* sync,
                       int mode);
     void subtract_single(float* id, float* qd, long np, float f0, int shift, float drift, const unsigned char* sym);
+    int fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
+                   unsigned* metric, unsigned* maxnp, unsigned char* data);
     int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);
     int decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
                         int* h_nout);

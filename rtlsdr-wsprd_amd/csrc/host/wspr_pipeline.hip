@@ -152,9 +152,9 @@ struct Context::Impl {
     hipStream_t stream = nullptr;
     int device = 0;
     DeviceTables tab{};
-    DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter;
+    DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists, scrsync, psavg;
+        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
@@ -162,7 +162,7 @@ struct Context::Impl {
     // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
-    double t_ms[12] = {0};           // stage times (ms) and Fano statistics of the last batch
+    double t_ms[16] = {0};           // stage times (ms) and Fano statistics of the last batch
     std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -225,6 +225,11 @@ Context::Context(int nslots) : d(new Impl) {
     upload(d->t_lpf.need(lpf.size() * 4), lpf.data(), lpf.size() * 4, d->stream);
     upload(d->t_part.need(part.size() * 4), part.data(), part.size() * 4, d->stream);
     upload(d->t_jitter.need(sizeof d->jitter_ladder), d->jitter_ladder, sizeof d->jitter_ladder, d->stream);
+    {
+        static short metric0[256];
+        for (int i = 0; i < 256; ++i) metric0[i] = (short)default_metrics().tab[0][i];
+        upload(d->t_metric0.need(sizeof metric0), metric0, sizeof metric0, d->stream);
+    }
     HIP_OK(hipStreamSynchronize(d->stream));
     d->tab.window = d->t_window.as<float>();
     d->tab.twiddle = d->t_twiddle.as<float2>();
@@ -345,7 +350,7 @@ struct WaveItem {
     int seg, cand;
     // filled by the GPU wave
     FineState fine;
-    bool worth = false, decoded = false;
+    bool worth = false, decoded = false, rung0_pending = false;
     int  jitter = 0;
     unsigned cycles = 0;
     unsigned char decdata[11];
@@ -386,8 +391,23 @@ static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, in
     return next;
 }
 
+// Fano work split.  A soft-symbol vector that decodes almost always does so within
+// a few hundred cycles; one that does not costs the full 810 000-cycle time-out (wsprd.c:431,
+// fano.c:149-153), milliseconds of a CPU core, and crowded bands produce thousands of those.
+// The host pool therefore runs every attempt with a SMALL budget and treats "not finished" as a
+// provisional failure, so that the batch keeps moving; the unfinished attempts are completed, with
+// the reference's full budget, by the device Fano kernel (K6) at the end.  If any of them turns
+// out to decode after all -- which would have changed what the reference did next -- the segment
+// is decoded again from its original IQ with the host running the full budget, so the final
+// spots are exactly the reference's.  WSPR_FANO_FAST = cycles-per-bit of the fast budget
+// (default 600 = 48 600 cycles; 0 disables the split).
+std::atomic<unsigned>& fano_fast_budget() {
+    static std::atomic<unsigned> v{[] { const char* e = getenv("WSPR_FANO_FAST"); return e ? (unsigned)atoi(e) : 600u; }()};
+    return v;
+}
+
 int Context::decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
-                             int max_results, int* n_results) {
+                             int max_results, int* n_results, const std::function<void(const std::vector<int>&)>& reload) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
     c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0;
@@ -397,13 +417,60 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     if (nseg <= 0) return 0;
     if (samples > kMaxSamples || blocks < 23) return 0;      // outside what the reference arrays allow
 
+    const unsigned fast_cfg = fano_fast_budget().load();
+    // small batches gain nothing from the split (their time-outs fit the host pool) and would pay
+    // the device kernel's latency
+    const unsigned fast = (reload && nseg >= 256) ? std::min(fast_cfg, 10000u) : 0u;
+    std::vector<int> all(nseg);
+    for (int s = 0; s < nseg; ++s) all[s] = s;
+    PendingFano pend;
+    decode_core(nseg, samples, opt, out, max_results, n_results, all, fast >= 10000u ? 0u : fast, pend);
+    if (!pend.seg.empty()) {
+        // ---- finish the provisional failures on the device, full budget ----------------------
+        const auto t_t0 = std::chrono::steady_clock::now();
+        const int np = (int)pend.seg.size();
+        std::vector<int> ret(np);
+        std::vector<unsigned> cyc(np), met(np), mnp(np);
+        std::vector<unsigned char> dat((size_t)np * 10);
+        fano_batch(pend.sym.data(), np, 10000u, ret.data(), cyc.data(), met.data(), mnp.data(), dat.data());
+        std::vector<char> dirty(nseg, 0);
+        for (int i = 0; i < np; ++i) {
+            c.n_fano++; c.n_cycles += cyc[i];
+            if (ret[i] == 0) dirty[pend.seg[i]] = 1; else c.n_timeout++;
+        }
+        c.t_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_t0).count();
+        std::vector<int> redo;
+        for (int s = 0; s < nseg; ++s) if (dirty[s]) redo.push_back(s);
+        c.t_ms[12] = np; c.t_ms[13] = (double)redo.size();
+        if (!redo.empty()) {
+            // ---- exact re-decode of the few segments where a late success changes the story ----
+            reload(redo);
+            PendingFano none;
+            decode_core(nseg, samples, opt, out, max_results, n_results, redo, 0u, none);
+        }
+    }
+    c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
+    c.t_ms[7] = (double)c.n_fano.load();
+    c.t_ms[8] = (double)c.n_timeout.load();
+    c.t_ms[9] = (double)c.n_cycles.load();
+    return 0;
+}
+
+// One full decode (all passes) of the segments in `active0`.  fast = 0: the host Fano pool runs the
+// reference's full cycle budget (exact on its own).  fast > 0: it runs `fast` cycles per bit and
+// records every attempt it could not finish in `pend` (see decode_resident).
+int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
+                         int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend) {
+    Impl& c = *d;
+    for (int s : active0) n_results[s] = 0;
+
     // tuning constants of wsprd.c:423-433
     const float minsync1 = 0.10f;
     float minsync2 = 0.12f;
     int maxdrift = 4;
     const float minrms = 52.0 * (50 / 64.0);
     const int delta = 60;
-    const unsigned maxcycles = 10000;
+    const unsigned maxcycles = fast ? fast : 10000u;
     const int lagstep = opt.quickmode ? 16 : 8;
     const int nlag0 = 256 / lagstep + 1;
     const int njit_rest = opt.quickmode ? 0 : kMaxLags - 1;
@@ -443,8 +510,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     std::vector<SegBook> book(nseg);
     std::vector<int> npk;
     std::vector<DevCand> cand;
-    std::vector<int> active(nseg);
-    for (int s = 0; s < nseg; ++s) active[s] = s;
+    std::vector<int> active = active0;
 
     for (int ipass = 0; ipass < opt.npasses; ++ipass) {
         if (ipass == 1) {                                      // wsprd.c:522-523
@@ -584,10 +650,15 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     memset(w.decdata, 0, sizeof w.decdata);
                     const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
                     w.decoded = (nd == 0);
-                    c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++;
+                    w.rung0_pending = (nd != 0) && fast;
+                    if (!w.rung0_pending) { c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++; }
                 }
             }, nw >= 256 ? 1 : 0);
             c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
+
+            if (fast)
+                for (int i = 0; i < nw; ++i)
+                    if (wave[i].rung0_pending) pend.add(wave[i].seg, h_sym + (size_t)i * kNSymD);
 
             // ---- remaining rungs, only for candidates that still need them --------
             std::vector<int> again;
@@ -617,7 +688,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                 const auto t_f1 = std::chrono::steady_clock::now();
                 // every (candidate, rung) Fano attempt is independent; the ladder keeps the
                 // FIRST success in rung order, so run them all and pick afterwards
-                struct Attempt { int ok; unsigned cycles; unsigned char data[11]; };
+                struct Attempt { int ok; int pending; unsigned cycles; unsigned char data[11]; };
                 std::vector<Attempt> att((size_t)na * njit_rest);
                 std::vector<std::atomic<int>> first(na);
                 for (auto& f : first) f.store(njit_rest);
@@ -630,6 +701,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     const int idx = a * njit_rest + r;
                     Attempt& at = att[idx];
                     at.ok = 0;
+                    at.pending = 0;
                     if (r > first[a].load()) return;           // an earlier rung already decoded
                     const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
                     if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
@@ -639,13 +711,23 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                     unsigned metric, maxnp;
                     memset(at.data, 0, sizeof at.data);
                     const int nd = fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles);
-                    c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++;
+                    at.pending = (nd != 0) && fast;
+                    if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
                     if (nd == 0) {
                         at.ok = 1;
                         int cur = first[a].load();
                         while (r < cur && !first[a].compare_exchange_weak(cur, r)) {}
                     }
                 }, 1);
+                if (fast)      // unfinished attempts on rungs BEFORE the accepted one decide nothing yet
+                    for (int a = 0; a < na; ++a) {
+                        const int rmax = std::min(first[a].load(), njit_rest);
+                        for (int r = 0; r < rmax; ++r)
+                            if (att[(size_t)a * njit_rest + r].pending) {
+                                const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
+                                pend.add(wave[again[a]].seg, h_sym + g * kNSymD);
+                            }
+                    }
                 for (int a = 0; a < na; ++a) {
                     const int r = first[a].load();
                     if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
@@ -748,7 +830,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     }
 
     // results strongest first (wsprd.c:827; stable like glibc's merge sort)
-    for (int s = 0; s < nseg; ++s) {
+    for (int s : active0) {
         SegBook& bk = book[s];
         const int n = std::min(bk.uniques, max_results);
         decoder_results* o = out + (size_t)s * max_results;
@@ -769,15 +851,11 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
         }
         memset(hashtab_of(0), 0, per_seg);                   // the arena is reused by later batches
     }
-    c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
-    c.t_ms[7] = (double)c.n_fano.load();
-    c.t_ms[8] = (double)c.n_timeout.load();
-    c.t_ms[9] = (double)c.n_cycles.load();
     return 0;
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 12);
+    const int n = std::min(cap, 14);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }
@@ -836,6 +914,44 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return 1;
+}
+
+// Device Fano search over n host vectors: interleaved soft symbols in, results out
+int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
+                        unsigned* metric, unsigned* maxnp, unsigned char* data) {
+    Impl& c = *d;
+    if (n <= 0) return 0;
+    std::vector<int> off(n);
+    for (int i = 0; i < n; ++i) off[i] = i;
+    unsigned char* dsym = static_cast<unsigned char*>(c.fz_sym.need((size_t)n * kNSymD));
+    int* doff = static_cast<int*>(c.fz_off.need((size_t)n * 4));
+    int* dret = static_cast<int*>(c.fz_ret.need((size_t)n * 4));
+    unsigned* dcyc = static_cast<unsigned*>(c.fz_cyc.need((size_t)n * 4));
+    unsigned* dmet = static_cast<unsigned*>(c.fz_met.need((size_t)n * 4));
+    unsigned* dmax = static_cast<unsigned*>(c.fz_max.need((size_t)n * 4));
+    unsigned char* ddat = static_cast<unsigned char*>(c.fz_dat.need((size_t)n * 10));
+    upload(dsym, symbols, (size_t)n * kNSymD, c.stream);
+    upload(doff, off.data(), (size_t)n * 4, c.stream);
+    launch_fano_tail(dsym, doff, n, c.t_metric0.as<short>(), 60, maxcycles, dret, dcyc, dmet, dmax, ddat, c.stream);
+    HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(metric, dmet, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(maxnp, dmax, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
+    sync();
+    return 0;
+}
+
+// restore the original IQ of single segments (rows) of the working buffers
+void Context::reload_rows(const float* I, const float* Q, bool device, size_t stride, int samples,
+                          const std::vector<int>& segs) {
+    Impl& c = *d;
+    const hipMemcpyKind kind = device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int s : segs) {
+        HIP_OK(hipMemcpyAsync(c.iqI.as<float>() + (size_t)s * kIqStride, I + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));
+        HIP_OK(hipMemcpyAsync(c.iqQ.as<float>() + (size_t)s * kIqStride, Q + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));
+    }
+    if (!device) sync();       // pageable host memory: the copies must not outlive the caller's view
 }
 
 // ------------------------------------------------------- single-call stages --

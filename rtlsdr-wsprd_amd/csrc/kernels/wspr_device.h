@@ -25,6 +25,7 @@ constexpr int kPsStride   = 432;        // floats per (segment, time) row
 constexpr int kSmooth     = 411;        // smoothed-spectrum length
 constexpr int kMaxCand    = 200;
 constexpr int kNSymD      = 162;
+constexpr int kNBitsD     = 81;
 constexpr int kSps        = 256;
 constexpr int kSigLen     = kNSymD * kSps;   // 41 472 samples of signal
 constexpr int kLpfTaps    = 360;
@@ -114,6 +115,11 @@ void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nf
 size_t subtract_scratch_floats(int njobs);
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
                      float* scratch /* subtract_scratch_floats(njobs) */, const DeviceTables& t, hipStream_t st);
+// Device Fano search (K6) for n soft-symbol vectors symbols[offsets[i]*162 ...] (interleaved order, as
+// the demodulator writes them); metric0 = the 256-entry "sent 0" branch-metric row.
+void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, const short* metric0, int delta,
+                      unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
+                      unsigned char* data, hipStream_t st);
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
 void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
                      int* n_out, int32_t* scratch, hipStream_t st);

@@ -60,6 +60,43 @@ def test_config2_1024_segments_properties(env):
         assert all(abs(a[8] - _tup(b)[8]) < 1e-4 for a, b in zip(got, ref))
 
 
+def test_fano_budget_split_never_changes_results(env):
+    """Scheduler: host Fano with a short budget + device tail (K6) + exact re-decode of the segments
+    where a postponed attempt decodes after all == one pass with the reference's budget everywhere.
+    Marginal signals (-22..-30 dB, 4 per segment) with a 3 cycles/bit host budget force many
+    postponed attempts and many re-decoded segments."""
+    torch, bench, w, dev = env
+    nseg = 900                                           # 3 slots x 300: every slot takes the split path
+    I, Q, expected = bench.synth_batch_gpu(nseg, 77, dev, 4, -22.0, -30.0, 0.3)
+    L = w.lib()
+    L.wspr_set_fano_fast_budget.restype = C.c_uint
+    old = L.wspr_set_fano_fast_budget(C.c_uint(10000))  # split disabled: the exact schedule
+    try:
+        dec = w.BatchDecoder(nseg, 16)
+        dec.decode(I, Q)
+        exact = [[_tup(x) for x in dec.spots(s)] for s in range(nseg)]
+        assert w.last_timings()["fano_left_to_device"] == 0
+        for budget in (3, 40, 600):
+            L.wspr_set_fano_fast_budget(C.c_uint(budget))
+            dec.decode(I, Q)
+            got = [[_tup(x) for x in dec.spots(s)] for s in range(nseg)]
+            tm = w.last_timings()
+            print("budget %d: %d attempts left to the device, %d segments decoded again, tail %.1f ms" % (
+                budget, tm["fano_left_to_device"], tm["segments_redecoded"], tm["device_fano_tail_ms"]))
+            assert got == exact, budget
+            if budget == 3:
+                assert tm["fano_left_to_device"] > 100 and tm["segments_redecoded"] > 20
+    finally:
+        L.wspr_set_fano_fast_budget(C.c_uint(old))
+    assert sum(len(x) for x in exact) > nseg             # the workload really decodes
+    # at these SNRs the decoder itself yields the odd false decode (the oracle yields the same ones)
+    assert sum(m[0].decode() not in expected[s] for s in range(nseg) for m in exact[s]) <= 0.01 * sum(len(x) for x in exact)
+    hI, hQ = I.cpu().numpy(), Q.cpu().numpy()
+    for s in range(0, nseg, 150):                        # and the exact schedule is the oracle's
+        ref, _, _ = ol.decode(hI[s], hQ[s], NS)
+        assert [t[:8] + t[9:] for t in exact[s]] == [_tup(x)[:8] + _tup(x)[9:] for x in ref]
+
+
 def test_residual_no_longer_decodes(env):
     torch, bench, w, dev = env
     I, Q, expected = bench.synth_batch_gpu(64, 5, dev, 1, -15.0, -15.0, 0.5)
