@@ -265,7 +265,7 @@ def main():
     if rank == 0:
         total_spots = int(gathered[0].sum()) if gathered is not None else dec.total_spots()
         # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
-        ms = (C.c_double * 3)()
+        ms = (C.c_double * 8)()
         w.lib().wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20, C.addressof(ms))
         k1, k2, k3 = ms[0], ms[1], ms[2]
         traffic = None
@@ -276,6 +276,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic, "avg_launch_ms": k1, "bytes_per_launch": K1_BYTES * nseg,
                 "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
+                                   "wall_ms": ms[4],
                                    "bytes_per_launch": STAGE_BYTES * nseg,
                                    "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
                                    "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}

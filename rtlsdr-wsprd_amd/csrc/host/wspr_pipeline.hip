@@ -316,15 +316,33 @@ float* Context::ps_buffer(int nseg) {
 }
 
 // ---------------------------------------------------------------- stages -----
+// K1 + K2a over `nactive` segments; ev (optional): an event before and after each kernel
+static void fft_and_average(const float* dI, const float* dQ, const int* d_seglist, int nactive, int samples, float* ps,
+                            float* psavg, const DeviceTables& tab, hipStream_t st, std::vector<hipEvent_t>* ev = nullptr) {
+    const int blocks = 4 * (samples / kFftSize) - 1;
+    auto mark = [&] {
+        if (!ev) return;
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipEventRecord(e, st));
+        ev->push_back(e);
+    };
+    mark();
+    launch_fft_bank(dI, dQ, d_seglist, nactive, samples, ps, tab, st);
+    mark(); mark();
+    launch_time_average(ps, d_seglist, nactive, blocks, psavg, st);
+    mark();
+}
+
 void Context::run_fft_sync(int nseg, int samples, int maxdrift, bool coarse, const int* d_seglist, int nactive,
                            float* noise_out, float* smspec_out) {
     const int blocks = 4 * (samples / kFftSize) - 1;
     float* ps = ps_buffer(nseg);
     DevCand* cand = static_cast<DevCand*>(d->cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
     int* npk = static_cast<int*>(d->npk.need((size_t)nseg * 4));
-    launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), d_seglist, nactive, samples, ps, d->tab, d->stream);
     float* psavg = static_cast<float*>(d->psavg.need((size_t)nseg * kPsStride * 4));
-    launch_pick_peaks(ps, d_seglist, nactive, blocks, psavg, cand, npk, noise_out, smspec_out, d->tab, d->stream);
+    fft_and_average(d->iqI.as<float>(), d->iqQ.as<float>(), d_seglist, nactive, samples, ps, psavg, d->tab, d->stream);
+    launch_pick_peaks(ps, d_seglist, nactive, blocks, psavg, cand, npk, noise_out, smspec_out, d->tab, d->stream, true);
     if (coarse) launch_coarse_sync(ps, d_seglist, nactive, blocks, cand, npk, maxdrift, d->tab, d->stream);
 }
 
@@ -860,34 +878,40 @@ int Context::last_timings(double* ms, int cap) {
     return n;
 }
 
-// average kernel durations of the FFT+sync stage, HIP events on the launch stream
+// average kernel durations of the FFT+sync stage, HIP events on the launch stream:
+// ms[0] = K1 (all chunks), ms[1] = K2 (time average of all chunks + peak picking), ms[2] = K3,
+// ms[3] = K1 launches per pass, ms[4] = wall time of the whole stage
 int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
     const int blocks = 4 * (samples / kFftSize) - 1;
     float* ps = ps_buffer(nseg);
     DevCand* cand = static_cast<DevCand*>(d->cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
     int* npk = static_cast<int*>(d->npk.need((size_t)nseg * 4));
-    std::vector<hipEvent_t> ev(4 * (size_t)iters);
-    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    float* psavg = static_cast<float*>(d->psavg.need((size_t)nseg * kPsStride * 4));
+    for (int k = 0; k < 5; ++k) ms[k] = 0.0;
+    auto between = [](hipEvent_t a, hipEvent_t b) { float t = 0; HIP_OK(hipEventElapsedTime(&t, a, b)); return (double)t; };
     for (int it = 0; it < iters; ++it) {
-        HIP_OK(hipEventRecord(ev[4 * it + 0], d->stream));
-        launch_fft_bank(d->iqI.as<float>(), d->iqQ.as<float>(), nullptr, nseg, samples, ps, d->tab, d->stream);
-        HIP_OK(hipEventRecord(ev[4 * it + 1], d->stream));
-        launch_pick_peaks(ps, nullptr, nseg, blocks, static_cast<float*>(d->psavg.need((size_t)nseg * kPsStride * 4)),
-                          cand, npk, nullptr, nullptr, d->tab, d->stream);
-        HIP_OK(hipEventRecord(ev[4 * it + 2], d->stream));
+        std::vector<hipEvent_t> ev;
+        fft_and_average(d->iqI.as<float>(), d->iqQ.as<float>(), nullptr, nseg, samples, ps, psavg, d->tab, d->stream, &ev);
+        hipEvent_t e1, e2, e3;
+        HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2)); HIP_OK(hipEventCreate(&e3));
+        HIP_OK(hipEventRecord(e1, d->stream));
+        launch_pick_peaks(ps, nullptr, nseg, blocks, psavg, cand, npk, nullptr, nullptr, d->tab, d->stream, true);
+        HIP_OK(hipEventRecord(e2, d->stream));
         launch_coarse_sync(ps, nullptr, nseg, blocks, cand, npk, 4, d->tab, d->stream);
-        HIP_OK(hipEventRecord(ev[4 * it + 3], d->stream));
-    }
-    HIP_OK(hipStreamSynchronize(d->stream));
-    ms[0] = ms[1] = ms[2] = 0.0;
-    for (int it = 0; it < iters; ++it)
-        for (int k = 0; k < 3; ++k) {
-            float t = 0;
-            HIP_OK(hipEventElapsedTime(&t, ev[4 * it + k], ev[4 * it + k + 1]));
-            ms[k] += t / iters;
+        HIP_OK(hipEventRecord(e3, d->stream));
+        HIP_OK(hipStreamSynchronize(d->stream));
+        for (size_t i = 0; i + 3 < ev.size(); i += 4) {
+            ms[0] += between(ev[i], ev[i + 1]) / iters;
+            ms[1] += between(ev[i + 2], ev[i + 3]) / iters;
         }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    return 3;
+        ms[1] += between(e1, e2) / iters;
+        ms[2] += between(e2, e3) / iters;
+        ms[3] = (double)(ev.size() / 4);
+        ms[4] += between(ev[0], e3) / iters;
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+    }
+    return 5;
 }
 
 // average duration of the whole front end (K0 a/b/c + normalise) over `iters` launches

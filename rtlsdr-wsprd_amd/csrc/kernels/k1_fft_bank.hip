@@ -13,7 +13,12 @@
 //     sample is fetched from HBM/L2 once per wave (2 coalesced 256-B rows of I and
 //     of Q per FFT) and no LDS staging of the input is needed.
 //   * window and twiddles live in registers for the whole run.
-// Roofline: HBM-bound (algorithmic 938 796 B / segment / pass for ~9 MFLOP).
+//   * a complex point is one VGPR pair and every butterfly is written for the packed fp32 pipe
+//     (v_pk_add_f32 / v_pk_mul_f32 with op_sel broadcasts): five instructions per general
+//     butterfly, two to four for the trivial twiddles of the last pass; the run loop is unrolled
+//     by four so the sliding sample window rotates by renaming instead of register moves.
+// Roofline: HBM-bound (algorithmic 938 796 B / segment / pass for ~9 MFLOP); at ~210 packed VALU
+// instructions per FFT the vector pipe is the next limit, not far behind.
 //
 // The butterfly arithmetic (u+v, (u-v)*w with separately rounded products) is the
 // same as the CPU oracle's orc_fft512(), so results are bit-identical to it.
@@ -28,50 +33,67 @@ namespace {
 constexpr int kWavesPerWg    = 4;
 constexpr int kTile          = 576;     // complex words of LDS per wave
 
-__device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
-    const float dr = u.x - v.x, di = u.y - v.y;
-    u.x = u.x + v.x;
-    u.y = u.y + v.y;
-    const float t1 = dr * w.x, t2 = di * w.y, t3 = dr * w.y, t4 = di * w.x;
-    v.x = t1 - t2;
-    v.y = t3 + t4;
+typedef float v2 __attribute__((ext_vector_type(2)));   // (re, im): one VGPR pair, v_pk_*_f32 operands
+
+// General radix-2 DIF butterfly  u' = u + v,  v' = (u - v) * w  with the four products rounded
+// separately (t1 = dr*wx, t2 = di*wy, t3 = dr*wy, t4 = di*wx; v' = (t1 - t2, t3 + t4)), exactly the
+// oracle's orc_fft512().  Five packed instructions: wn = (-wy, wx) turns the mixed subtract/add
+// into one packed add, since di*(-wy) = -(di*wy) and t1 + (-t2) = t1 - t2 bit for bit.
+__device__ __forceinline__ void bfly(v2& u, v2& v, const v2 w, const v2 wn) {
+    const v2 d = u - v;
+    u = u + v;
+    const v2 p = d.xx * w;
+    const v2 q = d.yy * wn;
+    v = p + q;
 }
 
-// three DIF stages on the 8 register-resident points; tw[0..3] stage a (pairs r,r+4),
-// tw[4..5] stage b (pairs r,r+2), tw[6] stage c (pairs r,r+1)
-__device__ __forceinline__ void pass3(float2 (&x)[8], const float2 (&tw)[7]) {
-    bfly(x[0], x[4], tw[0]); bfly(x[1], x[5], tw[1]); bfly(x[2], x[6], tw[2]); bfly(x[3], x[7], tw[3]);
-    bfly(x[0], x[2], tw[4]); bfly(x[1], x[3], tw[5]); bfly(x[4], x[6], tw[4]); bfly(x[5], x[7], tw[5]);
-    bfly(x[0], x[1], tw[6]); bfly(x[2], x[3], tw[6]); bfly(x[4], x[5], tw[6]); bfly(x[6], x[7], tw[6]);
+struct Tw {
+    v2 w[7], wn_[7];
+    __device__ __forceinline__ v2 wn(int k) const { return wn_[k]; }
+};
+__device__ __forceinline__ void set_tw(Tw& t, int k, const float2 f) {
+    t.w[k] = v2{f.x, f.y};
+    t.wn_[k] = v2{-f.y, f.x};
+}
+
+// three DIF stages on the 8 register-resident points; tw 0..3 stage a (pairs r,r+4),
+// 4..5 stage b (pairs r,r+2), 6 stage c (pairs r,r+1)
+__device__ __forceinline__ void pass3(v2 (&x)[8], const Tw& t) {
+    bfly(x[0], x[4], t.w[0], t.wn(0)); bfly(x[1], x[5], t.w[1], t.wn(1));
+    bfly(x[2], x[6], t.w[2], t.wn(2)); bfly(x[3], x[7], t.w[3], t.wn(3));
+    bfly(x[0], x[2], t.w[4], t.wn(4)); bfly(x[1], x[3], t.w[5], t.wn(5));
+    bfly(x[4], x[6], t.w[4], t.wn(4)); bfly(x[5], x[7], t.w[5], t.wn(5));
+    bfly(x[0], x[1], t.w[6], t.wn(6)); bfly(x[2], x[3], t.w[6], t.wn(6));
+    bfly(x[4], x[5], t.w[6], t.wn(6)); bfly(x[6], x[7], t.w[6], t.wn(6));
 }
 
 // The last three stages only meet the twiddles 1, -i and (1-i)/sqrt2, (-1-i)/sqrt2.  Written
 // out, the general butterfly reduces to the forms below with every surviving operation rounded
-// exactly as in the general formula (x*1 = x, x*0 = +-0 adds exactly, -(a*b) = a*(-b)), so the
-// bits are those of the general radix-2 butterfly the CPU oracle runs.
-__device__ __forceinline__ void bfly_one(float2& u, float2& v) {            // w = 1
-    const float dr = u.x - v.x, di = u.y - v.y;
-    u.x = u.x + v.x; u.y = u.y + v.y;
-    v.x = dr; v.y = di;
+// exactly as in the general formula (x*1 = x, x*0 = +-0 adds exactly, -(a*b) = a*(-b),
+// x - y = x + (-y)), so the bits are those of the general radix-2 butterfly the CPU oracle runs.
+__device__ __forceinline__ void bfly_one(v2& u, v2& v) {            // w = 1
+    const v2 d = u - v;
+    u = u + v;
+    v = d;
 }
-__device__ __forceinline__ void bfly_mi(float2& u, float2& v) {             // w = -i
-    const float dr = u.x - v.x, di = u.y - v.y;
-    u.x = u.x + v.x; u.y = u.y + v.y;
-    v.x = di; v.y = -dr;
+__device__ __forceinline__ void bfly_mi(v2& u, v2& v) {             // w = -i : v' = (di, -dr)
+    const v2 d = u - v;
+    u = u + v;
+    v = v2{d.y, -d.x};
 }
-__device__ __forceinline__ void bfly_w8(float2& u, float2& v, float c) {    // w = (c, -c)
-    const float dr = u.x - v.x, di = u.y - v.y;
-    u.x = u.x + v.x; u.y = u.y + v.y;
-    const float a = dr * c, b = di * c;
-    v.x = a + b; v.y = b - a;
+__device__ __forceinline__ void bfly_w8(v2& u, v2& v, float c) {    // w = (c, -c) : v' = (a + b, b - a)
+    const v2 d = u - v;
+    u = u + v;
+    const v2 m = d * c;                                              // (a, b)
+    v = m + v2{m.y, -m.x};
 }
-__device__ __forceinline__ void bfly_w83(float2& u, float2& v, float c) {   // w = (-c, -c)
-    const float dr = u.x - v.x, di = u.y - v.y;
-    u.x = u.x + v.x; u.y = u.y + v.y;
-    const float a = dr * c, b = di * c;
-    v.x = b - a; v.y = -a - b;
+__device__ __forceinline__ void bfly_w83(v2& u, v2& v, float c) {   // w = (-c, -c) : v' = (b - a, -a - b)
+    const v2 d = u - v;
+    u = u + v;
+    const v2 m = d * c;
+    v = v2{m.y, -m.x} + (-m);
 }
-__device__ __forceinline__ void pass3_last(float2 (&x)[8], float c) {
+__device__ __forceinline__ void pass3_last(v2 (&x)[8], float c) {
     bfly_one(x[0], x[4]); bfly_w8(x[1], x[5], c); bfly_mi(x[2], x[6]); bfly_w83(x[3], x[7], c);
     bfly_one(x[0], x[2]); bfly_mi(x[1], x[3]);    bfly_one(x[4], x[6]); bfly_mi(x[5], x[7]);
     bfly_one(x[0], x[1]); bfly_one(x[2], x[3]);   bfly_one(x[4], x[5]); bfly_one(x[6], x[7]);
@@ -79,12 +101,64 @@ __device__ __forceinline__ void pass3_last(float2 (&x)[8], float c) {
 
 __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 
+// One FFT of the run: window, 3 passes, power, store.  `raw` is the sliding window of raw
+// samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block instead of
+// moving registers needs the run loop unrolled by 4 (kBase is a compile-time constant).
+template <int kBase>
+__device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], const Tw& twA, const Tw& twB, float w8,
+                                        v2* __restrict__ X, int lane, int a, int c,
+                                        const float* __restrict__ si, const float* __restrict__ sq, int t, bool more,
+                                        float* __restrict__ out) {
+    v2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = raw[(kBase + r) & 7] * win[r];
+
+    // slide the raw window by one hop (two 64-sample rows) while the FFT runs
+    if (more) {
+        const int k = kHop * (t + 1) + 384 + lane;
+        raw[(kBase + 0) & 7] = v2{si[k], sq[k]};
+        raw[(kBase + 1) & 7] = v2{si[k + 64], sq[k + 64]};
+    }
+
+    pass3(x, twA);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * r + lane] = x[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = X[72 * a + 8 * r + c];
+    __builtin_amdgcn_wave_barrier();
+
+    pass3(x, twB);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * a + 9 * r + c] = x[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = X[9 * lane + r];
+    __builtin_amdgcn_wave_barrier();
+
+    pass3_last(x, w8);
+
+    // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane)
+    float* __restrict__ row = out + (size_t)t * kPsStride;
+    const int lo = (int)rev6((unsigned)lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
+        const int bin = ((64 * rev3 + lo) + kFftSize / 2) & (kFftSize - 1);   // fft-shift
+        const int col = bin - kPsBin0;
+        if (col >= 0 && col < kPsBins) {
+            const v2 e = x[r] * x[r];
+            row[col] = e.x + e.y;
+        }
+    }
+}
+
 template <int kBlocksPerWave>
 __global__ __launch_bounds__(256)
 void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                      const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
                      const float* __restrict__ window, const float2* __restrict__ twiddle) {
-    __shared__ float2 tile[kWavesPerWg * kTile];
+    __shared__ v2 tile[kWavesPerWg * kTile];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
     const int t_begin = (blockIdx.x * kWavesPerWg + wave) * kBlocksPerWave;
@@ -94,74 +168,42 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
     const float* __restrict__ si = dI + (size_t)seg * kIqStride;
     const float* __restrict__ sq = dQ + (size_t)seg * kIqStride;
     float* __restrict__ out = ps + (size_t)seg * kMaxBlocks * kPsStride;
-    float2* X = tile + wave * kTile;
+    v2* X = tile + wave * kTile;
 
     const int a = lane >> 3, c = lane & 7;
     float win[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) win[r] = window[64 * r + lane];
     // pass A: element n = 64 r + lane ; pass B: n = 64 a + 8 r + c ; pass C: n = 8 lane + r
-    const float2 twA[7] = {twiddle[lane], twiddle[64 + lane], twiddle[128 + lane], twiddle[192 + lane],
-                           twiddle[2 * lane], twiddle[128 + 2 * lane], twiddle[4 * lane]};
-    const float2 twB[7] = {twiddle[8 * c], twiddle[64 + 8 * c], twiddle[128 + 8 * c], twiddle[192 + 8 * c],
-                           twiddle[16 * c], twiddle[128 + 16 * c], twiddle[32 * c]};
+    Tw twA, twB;
+    set_tw(twA, 0, twiddle[lane]);     set_tw(twA, 1, twiddle[64 + lane]);
+    set_tw(twA, 2, twiddle[128 + lane]); set_tw(twA, 3, twiddle[192 + lane]);
+    set_tw(twA, 4, twiddle[2 * lane]); set_tw(twA, 5, twiddle[128 + 2 * lane]);
+    set_tw(twA, 6, twiddle[4 * lane]);
+    set_tw(twB, 0, twiddle[8 * c]);    set_tw(twB, 1, twiddle[64 + 8 * c]);
+    set_tw(twB, 2, twiddle[128 + 8 * c]); set_tw(twB, 3, twiddle[192 + 8 * c]);
+    set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
+    set_tw(twB, 6, twiddle[32 * c]);
     const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
 
-    float ri[8], rq[8];
+    v2 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int k = kHop * t_begin + 64 * r + lane;
-        ri[r] = si[k];
-        rq[r] = sq[k];
+        raw[r] = v2{si[k], sq[k]};
     }
 
-    for (int t = t_begin; t < t_end; ++t) {
-        float2 x[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = make_float2(ri[r] * win[r], rq[r] * win[r]);
-
-        // slide the raw window by one hop (two 64-sample rows) while the FFT runs
-        if (t + 1 < t_end) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) { ri[r] = ri[r + 2]; rq[r] = rq[r + 2]; }
-            const int k = kHop * (t + 1) + 384 + lane;
-            ri[6] = si[k];      rq[6] = sq[k];
-            ri[7] = si[k + 64]; rq[7] = sq[k + 64];
-        }
-
-        pass3(x, twA);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) X[72 * r + lane] = x[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = X[72 * a + 8 * r + c];
-        __builtin_amdgcn_wave_barrier();
-
-        pass3(x, twB);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) X[72 * a + 9 * r + c] = x[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = X[9 * lane + r];
-        __builtin_amdgcn_wave_barrier();
-
-        pass3_last(x, w8);
-
-        // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane)
-        float* __restrict__ row = out + (size_t)t * kPsStride;
-        const int lo = (int)rev6((unsigned)lane);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
-            const int bin = ((64 * rev3 + lo) + kFftSize / 2) & (kFftSize - 1);   // fft-shift
-            const int col = bin - kPsBin0;
-            if (col >= 0 && col < kPsBins) {
-                const float e1 = x[r].x * x[r].x, e2 = x[r].y * x[r].y;
-                row[col] = e1 + e2;
-            }
-        }
+    for (int t = t_begin; t < t_end; t += 4) {
+        one_fft<0>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t, t + 1 < t_end, out);
+        if (t + 1 >= t_end) break;
+        one_fft<2>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 1, t + 2 < t_end, out);
+        if (t + 2 >= t_end) break;
+        one_fft<4>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 2, t + 3 < t_end, out);
+        if (t + 3 >= t_end) break;
+        one_fft<6>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 3, t + 4 < t_end, out);
     }
 }
+
 }  // namespace
 
 // Calibration helper for the HBM PMC counters: a plain 4-byte-per-lane stream copy, the
@@ -180,7 +222,7 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (blocks <= 0 || nseg_active <= 0) return;
     // consecutive FFTs per wave: longer runs re-read less input (run of R blocks loads R+3 hops)
-    static const int bpw = [] { const char* e = getenv("WSPR_K1_BLOCKS_PER_WAVE"); return e ? atoi(e) : 8; }();
+    static const int bpw = [] { const char* e = getenv("WSPR_K1_BLOCKS_PER_WAVE"); return e ? atoi(e) : 16; }();
 #define WSPR_K1(R)                                                                                          \
     do {                                                                                                    \
         const int per_wg = R * kWavesPerWg;                                                                 \
@@ -189,10 +231,10 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
                            t.window, t.twiddle);                                                            \
     } while (0)
     if (bpw == 12) WSPR_K1(12);
-    else if (bpw == 16) WSPR_K1(16);
+    else if (bpw == 8) WSPR_K1(8);
     else if (bpw == 22) WSPR_K1(22);
     else if (bpw == 4) WSPR_K1(4);
-    else WSPR_K1(8);
+    else WSPR_K1(16);
 #undef WSPR_K1
 }
 

@@ -8,6 +8,7 @@
 // an argmax is accumulated by ONE lane in the reference's loop order; lanes
 // parallelise over independent sums (bins, or (freq, lag, drift) hypotheses).
 #include "wspr_device.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -30,13 +31,14 @@ void time_average_kernel(const float* __restrict__ ps, const int* __restrict__ s
     constexpr int kRow4 = kPsStride / 4;
     // four independent serial chains per lane; batch the loads ahead of the adds
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    constexpr int kUnroll = 8;
     int t = 0;
-    for (; t + 8 <= blocks; t += 8) {
-        float4 v[8];
+    for (; t + kUnroll <= blocks; t += kUnroll) {
+        float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = P[(size_t)(t + u) * kRow4];
+        for (int u = 0; u < kUnroll; ++u) v[u] = P[(size_t)(t + u) * kRow4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        for (int u = 0; u < kUnroll; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     for (; t < blocks; ++t) { const float4 v = P[(size_t)t * kRow4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     *reinterpret_cast<float4*>(psavg + (size_t)seg * kPsStride + col) = acc;
@@ -267,12 +269,18 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
 }
 }  // namespace
 
-void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
-                       DevCand* cand, int* npk, float* noise_out, float* smspec_out,
-                       const DeviceTables& t, hipStream_t st) {
+void launch_time_average(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
+                         hipStream_t st) {
     if (nseg_active <= 0) return;
     hipLaunchKernelGGL(time_average_kernel, dim3((kPsBins + 255) / 256, nseg_active), dim3(64), 0, st, ps, seg_list,
                        blocks, psavg);
+}
+
+void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
+                       DevCand* cand, int* npk, float* noise_out, float* smspec_out,
+                       const DeviceTables& t, hipStream_t st, bool have_avg) {
+    if (nseg_active <= 0) return;
+    if (!have_avg) launch_time_average(ps, seg_list, nseg_active, blocks, psavg, st);
     hipLaunchKernelGGL(pick_peaks_kernel, dim3(nseg_active), dim3(512), 0, st, psavg, seg_list,
                        cand, npk, noise_out, smspec_out, t.min_snr, t.floor_snr);
 }

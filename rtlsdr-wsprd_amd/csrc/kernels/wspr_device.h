@@ -77,9 +77,13 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
                      int samples, float* ps, const DeviceTables& t, hipStream_t st);
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
 // psavg: scratch, nseg * kPsStride floats (time-averaged spectrum per segment)
+// K2a alone: psavg[seg][kPsStride] = sum over time blocks of ps, in block order (wsprd.c:556-561)
+void launch_time_average(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
+                         hipStream_t st);
+// have_avg: psavg was already filled by launch_time_average
 void launch_pick_peaks(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
                        DevCand* cand, int* npk, float* noise_out, float* smspec_out,
-                       const DeviceTables& t, hipStream_t st);
+                       const DeviceTables& t, hipStream_t st, bool have_avg = false);
 void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, int blocks,
                         DevCand* cand, const int* npk, int maxdrift,
                         const DeviceTables& t, hipStream_t st);

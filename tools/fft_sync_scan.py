@@ -11,9 +11,9 @@ L = w.lib()
 I, Q, _ = bench.synth_batch_gpu(2048, 7, dev, 1, -20.0, -20.0, 1.0)
 torch.cuda.synchronize()
 for nseg in (128, 256, 512, 1024, 2048):
-    ms = (C.c_double * 3)()
+    ms = (C.c_double * 8)()
     L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, 45000, I.stride(0), 20, C.addressof(ms))
-    tot = sum(ms)
-    print("nseg %5d  k1 %.1f us  k2 %.1f us  k3 %.1f us  | per-seg ns %.1f  stage GB/s %.0f  K1 GB/s %.0f" % (
-        nseg, ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3, tot * 1e6 / nseg, bench.STAGE_BYTES * nseg / tot / 1e6,
-        bench.K1_BYTES * nseg / ms[0] / 1e6))
+    tot = ms[0] + ms[1] + ms[2]
+    print("nseg %5d  k1 %.1f us (%d launches)  k2 %.1f us  k3 %.1f us  wall %.1f us | per-seg ns %.1f  stage GB/s %.0f (wall %.0f)  K1 GB/s %.0f" % (
+        nseg, ms[0] * 1e3, int(ms[3]), ms[1] * 1e3, ms[2] * 1e3, ms[4] * 1e3, tot * 1e6 / nseg,
+        bench.STAGE_BYTES * nseg / tot / 1e6, bench.STAGE_BYTES * nseg / ms[4] / 1e6, bench.K1_BYTES * nseg / ms[0] / 1e6))

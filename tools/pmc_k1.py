@@ -17,6 +17,6 @@ src = torch.rand(n, device=dev); dst = torch.empty_like(src)
 I, Q, _ = bench.synth_batch_gpu(1024, 99, dev, 1, -20.0, -20.0, 1.0)
 torch.cuda.synchronize()
 L.wspr_calib_copy(src.data_ptr(), dst.data_ptr(), n, 3)
-ms = (C.c_double * 3)()
+ms = (C.c_double * 8)()
 L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), 1024, 45000, I.stride(0), 5, C.addressof(ms))
 print("k1 k2 k3 ms:", list(ms))
