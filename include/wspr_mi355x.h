@@ -94,6 +94,30 @@ int wspr_decimate_u8(const uint8_t *iq, size_t nbytes, float *I, float *Q, uint3
  * wspr_iq_stride() floats), normalised, ready for wspr_decode_batch_device. */
 int wspr_decimate_u8_batch_device(const void *d_raw, size_t bytes_per_seg, int nseg,
                                   void *d_idat, void *d_qdat, int normalise);
+
+/* Streaming form of the front end.  The reference keeps the decimator state in `static` variables
+ * of rtlsdr_callback() (rtlsdr_wsprd.c:135-160: integrators, comb delay lines, FIR line, decimation
+ * counter), so it runs on across callbacks and across 2-minute segments; this state object carries
+ * exactly that between calls.  All-zero = the receiver at start-up.  Fields: samples into the open
+ * decimation block, integrators I1/I2 per rail (I, Q), and the second integrator at the last 36
+ * decimation instants (from which both combs and the FIR history follow). */
+typedef struct wspr_decim_state {
+    uint32_t phase;
+    uint32_t x1[2], x2[2];
+    uint32_t hist[2][36];
+} wspr_decim_state;
+void wspr_decim_stream_reset(wspr_decim_state *st);
+/* One callback's worth of samples (rtlsdr_wsprd.c:126: `buf`, `len`; nbytes a multiple of 16, the
+ * mixer phase restarts with every call as in the reference): appends the new outputs to I/Q at
+ * index `fill`, never beyond `capacity` (rtlsdr_wsprd.c:236-242), and updates the state.  Any
+ * chunking of a stream gives the same outputs as one call over the whole of it. */
+int wspr_decimate_u8_stream(wspr_decim_state *st, const uint8_t *iq, size_t nbytes, float *I, float *Q,
+                            uint32_t fill, uint32_t capacity, uint32_t *new_fill);
+/* Many receivers at once, resident data: row s of d_raw is the next bytes_per_seg bytes of receiver
+ * s, d_states[s] its state (device memory, read and updated), outputs start at column 0 of row s of
+ * d_idat/d_qdat (row stride wspr_iq_stride()), n_out[s] (host) = outputs produced. */
+int wspr_decimate_u8_batch_device_stateful(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_states,
+                                           void *d_idat, void *d_qdat, int *n_out);
 size_t wspr_iq_stride(void);        /* floats per segment row of device IQ buffers */
 
 /* ---- recorded files and the playback print format ----------- */

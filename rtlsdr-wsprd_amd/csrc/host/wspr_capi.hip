@@ -271,6 +271,29 @@ int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int n
     } catch (const std::exception& e) { return fail("wspr_decimate_u8_batch_device", e); }
 }
 
+int wspr_decimate_u8_batch_device_stateful(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_states,
+                                           void* d_idat, void* d_qdat, int* n_out) {
+    try {
+        if (!d_states || (bytes_per_seg & 15)) return -1;
+        return Context::get().decimate_device(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, 0, n_out,
+                                              static_cast<wspr::DecimState*>(d_states));
+    } catch (const std::exception& e) { return fail("wspr_decimate_u8_batch_device_stateful", e); }
+}
+
+void wspr_decim_stream_reset(wspr_decim_state* st) {
+    if (st) std::memset(st, 0, sizeof *st);
+}
+
+int wspr_decimate_u8_stream(wspr_decim_state* st, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
+                            uint32_t capacity, uint32_t* new_fill) {
+    static_assert(sizeof(wspr_decim_state) == sizeof(wspr::DecimState), "public and device state layouts differ");
+    try {
+        if (!st || (nbytes & 15)) return -1;
+        return Context::get().decimate_stream(reinterpret_cast<wspr::DecimState*>(st), iq, nbytes, I, Q, fill, capacity,
+                                              new_fill);
+    } catch (const std::exception& e) { return fail("wspr_decimate_u8_stream", e); }
+}
+
 int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t* n_out, int normalise) {
     try {
         Context& c = Context::get();

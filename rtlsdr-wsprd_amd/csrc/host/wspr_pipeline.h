@@ -68,7 +68,9 @@ public:
                    unsigned* metric, unsigned* maxnp, unsigned char* data);
     int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);
     int decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
-                        int* h_nout);
+                        int* h_nout, DecimState* d_states = nullptr);
+    int decimate_stream(DecimState* h_state, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
+                        uint32_t cap, uint32_t* new_fill);
 
     struct Impl;
     std::unique_ptr<Impl> d;

@@ -154,7 +154,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat;
+        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
@@ -1035,18 +1035,45 @@ void Context::subtract_single(float* id, float* qd, long np, float f0, int shift
 }
 
 int Context::decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
-                             int* h_nout) {
+                             int* h_nout, DecimState* d_states) {
     Impl& c = *d;
-    const size_t nblocks = bytes_per_seg / 2 / 6401;
+    const size_t nblocks = (size_t)decimate_blocks(bytes_per_seg / 2, d_states != nullptr);
     if (nblocks == 0) return -1;
     int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
     int* d_nv = static_cast<int*>(c.nvalid.need((size_t)nseg * 4));
-    HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, c.stream));
-    HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, c.stream));
-    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream);
+    if (!d_states) {                                          // whole segments: the unfilled tail must read as zero
+        HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, c.stream));
+        HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, c.stream));
+    }
+    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream, d_states);
     if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
     if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// one chunk of one receiver's stream: state in, appended outputs and state out (host buffers)
+int Context::decimate_stream(DecimState* h_state, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
+                             uint32_t cap, uint32_t* new_fill) {
+    Impl& c = *d;
+    if (nbytes == 0) { if (new_fill) *new_fill = fill; return 0; }
+    uint8_t* d_raw = static_cast<uint8_t*>(c.streamraw.need(nbytes + 16));
+    DecimState* d_st = static_cast<DecimState*>(c.streamstate.need(sizeof(DecimState)));
+    upload(d_raw, iq, nbytes, c.stream);
+    upload(d_st, h_state, sizeof(DecimState), c.stream);
+    float* wi = work_i(1);
+    float* wq = work_q(1);
+    int nout = 0;
+    const int rc = decimate_device(d_raw, nbytes, 1, wi, wq, 0, &nout, d_st);
+    if (rc) return rc;
+    HIP_OK(hipMemcpy(h_state, d_st, sizeof(DecimState), hipMemcpyDeviceToHost));
+    const uint32_t room = fill < cap ? cap - fill : 0u;
+    const uint32_t take = std::min<uint32_t>((uint32_t)nout, room);       // outputs beyond the capacity are dropped
+    if (take) {                                                            // (rtlsdr_wsprd.c:236-242)
+        HIP_OK(hipMemcpy(I + fill, wi, (size_t)take * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(Q + fill, wq, (size_t)take * 4, hipMemcpyDeviceToHost));
+    }
+    if (new_fill) *new_fill = fill + take;
     return 0;
 }
 

@@ -1,9 +1,11 @@
 // K0 -- receiver front end: fs/4 mixer + 2-stage CIC (R = 6401) + 33-tap FIR,
 // 2.4 Msps unsigned-8-bit IQ -> ~375 sps float32 IQ.
 //
-// Replaces reference rtlsdr_callback(), rtlsdr_wsprd.c:126-244 (zero initial
-// state per segment = the receiver at start-up).  Bound: HBM bandwidth -- one
-// pass over 576 000 000 B per 2-minute segment, ~0.02 op/B.
+// Replaces reference rtlsdr_callback(), rtlsdr_wsprd.c:126-244.  The reference keeps the
+// decimator state in `static` variables, i.e. it streams across callbacks and segments; here the
+// state is an explicit DecimState per receiver (null = zero state = the receiver at start-up), so
+// the same kernels serve a whole 2-minute buffer or a stream cut into arbitrary chunks.
+// Bound: HBM bandwidth -- one pass over 576 000 000 B per 2-minute segment, ~0.02 op/B.
 //
 // The streaming recurrences are restated as exact integer block sums.  With
 // x_r the mixed sample, R = 6401 and block b = samples [bR, (b+1)R):
@@ -16,6 +18,11 @@
 //   pass A (HBM-bound): block sums, one workgroup per pair of blocks, aligned 16-byte loads;
 //   pass B (tiny)     : the two integrators as parallel prefix sums over the 45 000 block sums;
 //   pass C (tiny)     : both combs + 33-tap compensation FIR, taps summed in reference order.
+// With a carried state, block 0 is the remainder of the block that was open when the previous
+// chunk ended (phase p samples already integrated: its weights simply start at R - p), the
+// integrators start from the carried values, the combs/FIR reach back into the last 36 carried
+// integrator samples, and a trailing partial block yields the state to carry on:
+//     I1_end = I1(last) + S_tail,   I2_end = I2(tail as if complete) - (R - n_tail) * I1_end.
 // Requirement: every segment row starts 16-byte aligned (bytes_per_seg % 16 == 0) and the buffer
 // is readable up to the next multiple of 16 bytes.
 #include "wspr_device.h"
@@ -51,16 +58,20 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 // neighbouring pair (the pair boundaries are not 16-byte aligned) are masked out.
 __global__ __launch_bounds__(256)
 void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks,
-                           int32_t* __restrict__ sums) {
+                           int32_t* __restrict__ sums, const DecimState* __restrict__ states) {
     __shared__ unsigned red[4][8];
     const int seg = blockIdx.y, pair = blockIdx.x, tid = threadIdx.x;
-    const int blkA = 2 * pair;
-    const bool haveB = (blkA + 1) < nblocks;
-    const long first = (long)pair * 2 * kR;                       // first sample of this pair
-    const long last = first + (haveB ? 2 * kR : kR);              // one past its last sample
     const long seg_samples = (long)(bytes_per_seg / 2);
+    const int phase = states ? (int)states[seg].phase : 0;
+    // blocks of this segment: with a state, every block the chunk touches (the last may be partial)
+    const int nb = states ? (int)((phase + seg_samples + kR - 1) / kR) : nblocks;
+    const int blkA = 2 * pair;
+    if (blkA >= nb) return;
+    const bool haveB = (blkA + 1) < nb;
+    const long first = (long)pair * 2 * kR - phase;               // first sample of this pair (< 0: carried over)
+    const long last = min(first + (haveB ? 2 * kR : kR), seg_samples);   // one past its last sample
     const uint4* __restrict__ vec = reinterpret_cast<const uint4*>(raw + (size_t)seg * bytes_per_seg);
-    const long v_lo = first >> 3, v_hi = (last + 7) >> 3;         // vectors touching [first, last)
+    const long v_lo = (first < 0 ? 0 : first) >> 3, v_hi = (last + 7) >> 3;   // vectors touching [first, last)
     const long v_max = (seg_samples + 7) >> 3;
 
     // all sums are modulo 2^32 (the reference's int32 integrators wrap): unsigned math
@@ -146,7 +157,7 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
     if (tid < 8) {
         const unsigned s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         const int blk = blkA + (tid >> 2);
-        if (blk < nblocks) sums[((size_t)seg * nblocks + blk) * 4 + (tid & 3)] = (int32_t)s;
+        if (blk < nb) sums[((size_t)seg * nblocks + blk) * 4 + (tid & 3)] = (int32_t)s;
     }
 }
 
@@ -170,80 +181,122 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* l
 }
 
 __global__ __launch_bounds__(kScanThreads)
-void cic_scan_kernel(const int32_t* __restrict__ sums, int nblocks, uint32_t* __restrict__ x2out) {
+void cic_scan_kernel(const int32_t* __restrict__ sums, int nblocks, size_t seg_samples, uint32_t* __restrict__ x2out,
+                     DecimState* __restrict__ states) {
     __shared__ unsigned lds[kScanThreads];
     const int seg = blockIdx.x, rail = blockIdx.y, tid = threadIdx.x;
     const int32_t* __restrict__ s = sums + (size_t)seg * nblocks * 4;
     uint32_t* __restrict__ out = x2out + ((size_t)seg * 2 + rail) * nblocks;
-    const int per = (nblocks + kScanThreads - 1) / kScanThreads;
-    const int lo = min(nblocks, tid * per), hi = min(nblocks, lo + per);
+    const int phase = states ? (int)states[seg].phase : 0;
+    const unsigned i1_0 = states ? states[seg].x1[rail] : 0u, i2_0 = states ? states[seg].x2[rail] : 0u;
+    const int nb = states ? (int)((phase + seg_samples + kR - 1) / kR) : nblocks;    // incl. a partial tail
+    const int nfull = states ? (int)((phase + seg_samples) / kR) : nblocks;
+    const unsigned mult0 = (unsigned)(kR - phase);                // block 0 only has R - phase samples left
+    const int per = (nb + kScanThreads - 1) / kScanThreads;
+    const int lo = min(nb, tid * per), hi = min(nb, lo + per);
 
     unsigned sumS = 0;
     for (int b = lo; b < hi; ++b) sumS += (unsigned)s[4 * b + rail];
-    const unsigned x1_start = block_exclusive_scan(sumS, lds, tid);      // I1 before block lo
+    const unsigned x1_start = i1_0 + block_exclusive_scan(sumS, lds, tid);     // I1 before block lo
 
     unsigned x1 = x1_start, sumT = 0;
     for (int b = lo; b < hi; ++b) {
-        sumT += (unsigned)kR * x1 + (unsigned)s[4 * b + 2 + rail];
+        sumT += (b == 0 ? mult0 : (unsigned)kR) * x1 + (unsigned)s[4 * b + 2 + rail];
         x1 += (unsigned)s[4 * b + rail];
     }
-    const unsigned x2_start = block_exclusive_scan(sumT, lds, tid);      // I2 before block lo
+    const unsigned x2_start = i2_0 + block_exclusive_scan(sumT, lds, tid);     // I2 before block lo
 
     x1 = x1_start;
     unsigned x2 = x2_start;
     for (int b = lo; b < hi; ++b) {
-        x2 += (unsigned)kR * x1 + (unsigned)s[4 * b + 2 + rail];
+        x2 += (b == 0 ? mult0 : (unsigned)kR) * x1 + (unsigned)s[4 * b + 2 + rail];
         x1 += (unsigned)s[4 * b + rail];
-        out[b] = x2;
+        if (b < nfull) out[b] = x2;
+        if (states && b == nb - 1) {                              // the integrators after the chunk's last sample
+            const unsigned n_tail = (unsigned)((phase + seg_samples) - (size_t)nfull * kR);
+            states[seg].x1[rail] = x1;
+            states[seg].x2[rail] = (nb > nfull) ? x2 - ((unsigned)kR - n_tail) * x1 : x2;
+        }
     }
 }
 
 // Two combs with a two-output delay (rtlsdr_wsprd.c:204-218): y2[b] = x2[b] - 2 x2[b-2] + x2[b-4]
 // (mod 2^32, zero before the start), then the 33-tap FIR: 32 previous comb outputs (oldest first)
 // on taps 0..31 and the new one on tap 32, summed in that order (rtlsdr_wsprd.c:220-234).
-__device__ __forceinline__ float comb_out(const uint32_t* __restrict__ x2, int b) {
-    if (b < 0) return 0.0f;
-    const uint32_t c0 = x2[b], c2 = (b >= 2) ? x2[b - 2] : 0u, c4 = (b >= 4) ? x2[b - 4] : 0u;
+// x2 at decimation instant b of this chunk; b < 0 reaches into the carried history (zero without one)
+__device__ __forceinline__ uint32_t x2_at(const uint32_t* __restrict__ x2, const uint32_t* __restrict__ hist, int b) {
+    if (b >= 0) return x2[b];
+    return (hist && b >= -kDecimHist) ? hist[kDecimHist + b] : 0u;
+}
+__device__ __forceinline__ float comb_out(const uint32_t* __restrict__ x2, const uint32_t* __restrict__ hist, int b) {
+    if (b < 0 && !hist) return 0.0f;
+    const uint32_t c0 = x2_at(x2, hist, b), c2 = x2_at(x2, hist, b - 2), c4 = x2_at(x2, hist, b - 4);
     const uint32_t y1 = c0 - c2, y1d = c2 - c4;       // y1[b], y1[b-2]
     return (float)(int32_t)(y1 - y1d);
 }
 
 __global__ __launch_bounds__(256)
-void cic_fir_kernel(const uint32_t* __restrict__ x2all, int nblocks, float* __restrict__ dI,
-                    float* __restrict__ dQ, int* __restrict__ n_out) {
+void cic_fir_kernel(const uint32_t* __restrict__ x2all, int nblocks, size_t seg_samples, float* __restrict__ dI,
+                    float* __restrict__ dQ, int* __restrict__ n_out, const DecimState* __restrict__ states) {
     const int seg = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m == 0 && n_out) n_out[seg] = nblocks < kMaxSamples ? nblocks : kMaxSamples;
-    if (m >= nblocks || m >= kMaxSamples) return;
+    const int nfull = states ? (int)((states[seg].phase + seg_samples) / kR) : nblocks;
+    if (m == 0 && n_out) n_out[seg] = nfull < kMaxSamples ? nfull : kMaxSamples;
+    if (m >= nfull || m >= kMaxSamples) return;
 #pragma unroll
     for (int rail = 0; rail < 2; ++rail) {
         const uint32_t* __restrict__ x2 = x2all + ((size_t)seg * 2 + rail) * nblocks;
+        const uint32_t* __restrict__ hist = states ? states[seg].hist[rail] : nullptr;
         float acc = 0.0f;
         for (int j = 0; j < 32; ++j) {
-            const float p = comb_out(x2, m - 32 + j) * kFirTaps[j];
+            const float p = comb_out(x2, hist, m - 32 + j) * kFirTaps[j];
             acc += p;
         }
-        const float p = comb_out(x2, m) * kFirTaps[32];
+        const float p = comb_out(x2, hist, m) * kFirTaps[32];
         acc += p;
         (rail == 0 ? dI : dQ)[(size_t)seg * kIqStride + m] = acc;
     }
 }
+
+// carry on: the last 36 integrator samples and the phase
+__global__ __launch_bounds__(128)
+void cic_carry_kernel(const uint32_t* __restrict__ x2all, int nblocks, size_t seg_samples, DecimState* __restrict__ states) {
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    DecimState& st = states[seg];
+    const int phase = (int)st.phase;
+    const int nfull = (int)((phase + seg_samples) / kR);
+    uint32_t v = 0;
+    const int rail = tid / kDecimHist, k = tid % kDecimHist;
+    if (tid < 2 * kDecimHist) {
+        const int i = nfull - kDecimHist + k;
+        v = (i >= 0) ? x2all[((size_t)seg * 2 + rail) * nblocks + i] : st.hist[rail][kDecimHist + i];
+    }
+    __syncthreads();
+    if (tid < 2 * kDecimHist) st.hist[rail][k] = v;
+    if (tid == 0) st.phase = (uint32_t)((phase + seg_samples) - (size_t)nfull * kR);
+}
 }  // namespace
 
-// scratch: nseg * nblocks * (4 int32 + 2 float)
+// blocks a chunk of nsamp samples can touch (scratch pitch); without a state only whole blocks count
+int decimate_blocks(size_t nsamp, bool stateful) {
+    return stateful ? (int)((nsamp + 2 * (size_t)kR - 2) / kR) : (int)(nsamp / kR);
+}
+
+// scratch: nseg * decimate_blocks() * (4 int32 + 2 uint32)
 void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
-                     int* n_out, int32_t* scratch, hipStream_t st) {
+                     int* n_out, int32_t* scratch, hipStream_t st, DecimState* states) {
     if (nseg <= 0) return;
     const size_t nsamp = bytes_per_seg / 2;
-    const int nblocks = (int)(nsamp / kR);
+    const int nblocks = decimate_blocks(nsamp, states != nullptr);
     if (nblocks <= 0) return;
     int32_t* sums = scratch;
     uint32_t* x2 = reinterpret_cast<uint32_t*>(scratch + (size_t)nseg * nblocks * 4);
     hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
-                       bytes_per_seg, nblocks, sums);
-    hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg, 2), dim3(kScanThreads), 0, st, sums, nblocks, x2);
-    hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, x2, nblocks,
-                       dI, dQ, n_out);
+                       bytes_per_seg, nblocks, sums, states);
+    hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg, 2), dim3(kScanThreads), 0, st, sums, nblocks, nsamp, x2, states);
+    hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, x2, nblocks, nsamp,
+                       dI, dQ, n_out, states);
+    if (states) hipLaunchKernelGGL(cic_carry_kernel, dim3(nseg), dim3(128), 0, st, x2, nblocks, nsamp, states);
 }
 
 }  // namespace wspr

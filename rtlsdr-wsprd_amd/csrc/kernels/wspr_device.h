@@ -125,7 +125,18 @@ void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, c
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
                       unsigned char* data, hipStream_t st);
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
+// Front-end state of one receiver between chunks of its sample stream (all zero at start-up):
+// samples into the open decimation block, both integrators per rail, and the integrator values at
+// the last 36 decimation instants (what the two combs and the 33-tap FIR still need).
+constexpr int kDecimHist = 36;
+struct DecimState {
+    uint32_t phase;
+    uint32_t x1[2], x2[2];
+    uint32_t hist[2][kDecimHist];
+};
+int decimate_blocks(size_t nsamp, bool stateful);
+// states: null = zero state, whole blocks only; else one DecimState per segment row, read and updated
 void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
-                     int* n_out, int32_t* scratch, hipStream_t st);
+                     int* n_out, int32_t* scratch, hipStream_t st, DecimState* states = nullptr);
 
 }  // namespace wspr

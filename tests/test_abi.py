@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     L = w.lib()
     funcs, data = declared_symbols()
     assert {"wspr_decode", "wspr_decode_batch", "wspr_decode_batch_device", "get_wspr_channel_symbols",
-            "sync_and_demodulate", "subtract_signal2", "fano", "unpk_", "nhash", "wspr_decimate_u8"} <= funcs
+            "sync_and_demodulate", "subtract_signal2", "fano", "unpk_", "nhash", "wspr_decimate_u8", "wspr_decimate_u8_stream",
+            "wspr_decim_stream_reset", "wspr_decimate_u8_batch_device_stateful", "wspr_set_fano_fast_budget"} <= funcs
     missing = [f for f in sorted(funcs | data) if not hasattr(L, f)]
     assert not missing, missing
 

@@ -246,6 +246,70 @@ def test_decimator_bit_exact_vs_oracle(w):
     assert np.array_equal(gi, oi) and np.array_equal(gq, oq)
 
 
+def _raw_stream(rng, nsamp, f0=40.0, amp=6.0):
+    n = np.arange(nsamp)
+    ph = 2 * np.pi * (-600000.0 + f0) / 2.4e6 * n
+    sig = amp * np.exp(1j * ph)
+    raw = np.empty(2 * nsamp, np.uint8)
+    raw[0::2] = np.clip(np.round(127.5 + sig.real + rng.normal(0, 10, nsamp)), 0, 255).astype(np.uint8)
+    raw[1::2] = np.clip(np.round(127.5 + sig.imag + rng.normal(0, 10, nsamp)), 0, 255).astype(np.uint8)
+    return raw
+
+
+class _DecimState(C.Structure):
+    _fields_ = [("phase", C.c_uint32), ("x1", C.c_uint32 * 2), ("x2", C.c_uint32 * 2), ("hist", (C.c_uint32 * 36) * 2)]
+
+
+def test_streaming_decimator_any_chunking_equals_oracle(w):
+    """The reference's decimator state is static (rtlsdr_wsprd.c:135-160): it streams across callbacks.
+    Chunks of 65536 bytes (the librtlsdr callback), of 16 bytes, shorter than one decimation block,
+    and random sizes must all give the oracle's streamed outputs bit for bit, including clipped bytes
+    (0x00 / 0xff) and a capacity that cuts the outputs off."""
+    rng = np.random.default_rng(21)
+    nsamp = 6401 * 90 + 3206                                 # a multiple of 8 samples
+    raw = _raw_stream(rng, nsamp)
+    raw[1000:1256] = 0                                       # int8 -128 negation case (SURVEY Q9)
+    raw[70000:70512] = 255
+    nbytes = raw.size
+    assert nbytes % 16 == 0
+    L = ol.lib()
+    GL = w.lib()
+    GL.wspr_decimate_u8_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_uint32, C.c_void_p]
+
+    def chunkings():
+        yield "callback", [65536] * (nbytes // 65536) + ([nbytes % 65536] if nbytes % 65536 else [])
+        yield "one", [nbytes]
+        sizes, left = [], nbytes
+        while left:
+            c = min(left, 16 * int(rng.integers(1, 3000)))
+            sizes.append(c); left -= c
+        yield "random", sizes
+        yield "tiny-then-rest", [16] * 40 + [6400 * 2 - 640] + [nbytes - 640 - (6400 * 2 - 640)]
+
+    for cap in (NS, 57):
+        for name, sizes in chunkings():
+            assert sum(sizes) == nbytes and all(c % 16 == 0 for c in sizes)
+            # the oracle is fed the same chunks: the mixer phase restarts with every call in both
+            st = L.orc_decim_new()
+            oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+            gi = np.zeros(NS, np.float32); gq = np.zeros(NS, np.float32)
+            gs = _DecimState()
+            GL.wspr_decim_stream_reset(C.byref(gs))
+            fill = 0; gfill = C.c_uint32(0); pos = 0
+            for c in sizes:
+                chunk = np.ascontiguousarray(raw[pos:pos + c])
+                fill = L.orc_decim_feed(C.c_void_p(st), ol.ptr(chunk), c, ol.ptr(oi), ol.ptr(oq), fill, cap)
+                assert GL.wspr_decimate_u8_stream(C.byref(gs), ol.ptr(chunk), c, ol.ptr(gi), ol.ptr(gq), gfill.value, cap,
+                                                  C.byref(gfill)) == 0
+                pos += c
+                assert gfill.value == fill, (name, pos)
+            L.orc_decim_free(C.c_void_p(st))
+            assert fill == min(cap, 90), (name, fill)
+            assert np.array_equal(gi, oi) and np.array_equal(gq, oq), name
+            assert gs.phase == nsamp % 6401
+
+
 # ------------------------------------------------------------------ message types 2 / 3, hash memory
 def _multi_segment(msgs, seed, snr=-8.0):
     rng = np.random.default_rng(seed)

@@ -142,3 +142,42 @@ def test_batched_device_decimator_equals_oracle(env):
                 assert np.array_equal(gi[s, :NS], oi) and np.array_equal(gq[s, :NS], oq)
             else:
                 assert np.array_equal(gi[s, :fill], oi[:fill]) and np.array_equal(gq[s, :fill], oq[:fill])
+
+
+def test_many_receivers_streaming_decimator_equals_oracle(env):
+    """Resident multi-receiver streaming: three receivers, three consecutive chunks each, one state per
+    receiver on the device; every chunk's outputs and the carried state behave as the oracle's stream."""
+    torch, bench, w, dev = env
+    rng = np.random.default_rng(5)
+    nrx, chunk_samples, nchunks = 3, 6401 * 40 + 1608, 3       # bytes per chunk divisible by 16
+    assert (2 * chunk_samples) % 16 == 0
+    streams = []
+    for s in range(nrx):
+        n = np.arange(chunk_samples * nchunks)
+        sig = (3.0 + 3.0 * s) * np.exp(2j * np.pi * (-600000.0 + 30.0 * (s - 1)) / 2.4e6 * n)
+        raw = np.empty(2 * n.size, np.uint8)
+        raw[0::2] = np.clip(np.round(127.5 + sig.real + rng.normal(0, 12, n.size)), 0, 255).astype(np.uint8)
+        raw[1::2] = np.clip(np.round(127.5 + sig.imag + rng.normal(0, 12, n.size)), 0, 255).astype(np.uint8)
+        streams.append(raw)
+    stride = int(w.lib().wspr_iq_stride())
+    states = torch.zeros(nrx, 77, dtype=torch.int32, device=dev)          # 308 bytes each, zero = start-up
+    dI = torch.zeros(nrx, stride, device=dev); dQ = torch.zeros(nrx, stride, device=dev)
+    L = ol.lib()
+    ost = [L.orc_decim_new() for _ in range(nrx)]
+    nb = 2 * chunk_samples
+    for c in range(nchunks):
+        d_raw = torch.from_numpy(np.stack([st[c * nb:(c + 1) * nb] for st in streams])).to(dev)
+        nout = (C.c_int * nrx)()
+        assert w.lib().wspr_decimate_u8_batch_device_stateful(
+            C.c_void_p(d_raw.data_ptr()), C.c_size_t(nb), nrx, C.c_void_p(states.data_ptr()), C.c_void_p(dI.data_ptr()),
+            C.c_void_p(dQ.data_ptr()), nout) == 0
+        gi, gq = dI.cpu().numpy(), dQ.cpu().numpy()
+        for s in range(nrx):
+            oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+            chunk = np.ascontiguousarray(streams[s][c * nb:(c + 1) * nb])
+            fill = L.orc_decim_feed(C.c_void_p(ost[s]), ol.ptr(chunk), nb, ol.ptr(oi), ol.ptr(oq), 0, NS)
+            assert nout[s] == fill and fill in (40, 41)
+            assert np.array_equal(gi[s, :fill], oi[:fill]) and np.array_equal(gq[s, :fill], oq[:fill]), (c, s)
+    assert states.cpu().numpy()[:, 0].tolist() == [(chunk_samples * nchunks) % 6401] * nrx
+    for st in ost:
+        L.orc_decim_free(C.c_void_p(st))
