@@ -175,11 +175,12 @@ int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int sa
  * Outputs per vector: ret (0 / -1), cycles, metric, maxnp, data[10]. */
 int wspr_fano_batch_device(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
                            unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data);
-/* Scheduler tuning (batches of >= 256 segments per slot): the host Fano pool gives every attempt
- * `cycles_per_bit` cycles per bit (default 600, env WSPR_FANO_FAST); attempts still running then are
- * finished by K6 with the reference's 10000, and a segment in which one of those decodes after all
- * is decoded again with the full budget everywhere, so results never depend on this value.
- * >= 10000 disables the split.  Returns the previous value. */
+/* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
+ * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with
+ * the reference's 10000, and a segment in which one of those decodes after all is decoded again with
+ * the full budget everywhere, so results never depend on this value.  Default 10000 = split off
+ * (env WSPR_FANO_FAST overrides); 600 pays once a batch carries thousands of Fano time-outs, K6's
+ * latency being 0.54 s whatever their number.  Returns the previous value. */
 unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
 /* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
  * ms[0] = average milliseconds per launch. */

@@ -420,7 +420,7 @@ static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, in
 // spots are exactly the reference's.  WSPR_FANO_FAST = cycles-per-bit of the fast budget
 // (default 600 = 48 600 cycles; 0 disables the split).
 std::atomic<unsigned>& fano_fast_budget() {
-    static std::atomic<unsigned> v{[] { const char* e = getenv("WSPR_FANO_FAST"); return e ? (unsigned)atoi(e) : 600u; }()};
+    static std::atomic<unsigned> v{[] { const char* e = getenv("WSPR_FANO_FAST"); return e ? (unsigned)atoi(e) : 10000u; }()};
     return v;
 }
 

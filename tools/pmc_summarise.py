@@ -14,6 +14,7 @@ def per_kernel(path, counter):
             continue
         name = r["Kernel_Name"]
         key = ("calib_copy" if "calib_copy" in name else "fft_bank" if "fft_bank" in name else
+               "time_average" if "time_average" in name else
                "pick_peaks" if "pick_peaks" in name else "coarse_sync" if "coarse_sync" in name else None)
         if key:
             acc[key].append(float(r["Counter_Value"]))
@@ -25,12 +26,13 @@ NSEG = 1024
 copy_bytes = 4 * (1 << 28)
 cal_r = copy_bytes / (fetch["calib_copy"] * 1024.0)
 cal_w = copy_bytes / (write["calib_copy"] * 1024.0)
-alg = {"fft_bank": (360000 + 4 * 417 * 347) * NSEG, "pick_peaks": 4 * 417 * 347 * NSEG, "coarse_sync": None}
+alg = {"fft_bank": (360000 + 4 * 417 * 347) * NSEG, "time_average": 4 * 417 * 347 * NSEG, "pick_peaks": None,
+       "coarse_sync": None}
 out = {"counter_unit": "KiB per dispatch", "calibration": {
     "kernel": "calib_copy_kernel, 1 GiB read + 1 GiB written, 4 B per lane",
     "FETCH_SIZE_KiB": fetch["calib_copy"], "WRITE_SIZE_KiB": write["calib_copy"],
     "true_bytes_per_counted_read_byte": cal_r, "true_bytes_per_counted_written_byte": cal_w}, "kernels": {}}
-for k in ("fft_bank", "pick_peaks", "coarse_sync"):
+for k in ("fft_bank", "time_average", "pick_peaks", "coarse_sync"):
     rb = fetch[k] * 1024.0 * cal_r
     wb = write[k] * 1024.0 * cal_w
     out["kernels"][k] = {"dispatches_averaged": nf[k], "FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write[k],
