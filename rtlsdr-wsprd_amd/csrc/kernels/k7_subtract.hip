@@ -6,12 +6,11 @@
 //   s'(t) = s(t) - c(t) r(t) / edge_norm.
 //
 // Three kernels, each keeping the reference's evaluation order where it matters:
-//   sub_phase_kernel   phi is the reference's *float* running sum (41 472 serial adds,
-//                      dphi changes every 256 samples).  One lane per job walks it; a wave
-//                      covers 64 jobs and transposes 64x64 blocks through LDS so that the
-//                      stores to HBM are coalesced rows.
-//   sub_ref_kernel     fully parallel: glibc-exact sincos of every phase (one shared
-//                      argument reduction), r and the products s*conj(r).
+//   sub_runs_kernel    phi is the reference's *float* running sum (41 472 serial adds, dphi
+//                      changes every 256 samples).  It is not walked: phase_runs.h decomposes
+//                      it exactly into ~200 linear runs per signal (one lane per job).
+//   sub_ref_kernel     fully parallel: every sample's phase from its run, glibc-exact sincos
+//                      (one shared argument reduction), r and the products s*conj(r).
 //   sub_filter_kernel  each low-pass output is one serial 360-term sum in tap order; a lane
 //                      owns 4 consecutive outputs and slides a 4-sample register window, the
 //                      tile is stored transposed-by-4 in LDS so the per-step read is
@@ -19,6 +18,7 @@
 // Bound: fp32 VALU (64 MFLOP of separately rounded mul/add per job), not HBM.
 #include "wspr_device.h"
 #include "glibc_sincosf.h"
+#include "phase_runs.h"
 
 #pragma clang fp contract(off)
 
@@ -27,59 +27,86 @@ namespace {
 
 constexpr double kTwoPiDt = 2.0 * 3.14159265358979323846 * 1.0 / 375.0;
 
-// scratch (floats): phiT[kSigLen][njobs_pad] (job fastest) | per job: ref[kSigLen] float2 | cc[kSigLen] float2
+// scratch (floats), per job: ref[kSigLen] float2 | cc[kSigLen] float2 | phase runs (PhaseTable)
 constexpr size_t kSubPerJob = 4 * (size_t)kSigLen;
-__host__ __device__ inline size_t jobs_padded(int njobs) { return ((size_t)njobs + 63) / 64 * 64; }
+struct PhaseTable {
+    PhaseRun runs[kPhaseMaxRuns];
+    float sym_phi[kNSymD];           // phase of the first sample of every symbol
+    float dphi[kNSymD];
+    uint16_t first_run[kNSymD + 2];  // first_run[0] == 0xffff: the runs did not fit, use sym_phi/dphi
+};
+static_assert(sizeof(PhaseTable) % 4 == 0, "PhaseTable is addressed in floats");
+constexpr size_t kTableFloats = sizeof(PhaseTable) / 4;
 
-// lane = job: the serial float phase walk; one coalesced 256-B store per step per wave
-__global__ __launch_bounds__(64)
-void sub_phase_kernel(const SubJob* __restrict__ jobs, int njobs, float* __restrict__ phiT) {
-    const int job = blockIdx.x * 64 + threadIdx.x;
-    const SubJob* jb = jobs + (job < njobs ? job : 0);
-    const float f0 = jb->f0, drift = jb->drift;
-    const size_t pitch = jobs_padded(njobs);
-    float* __restrict__ out = phiT + job;
-    float phi = 0.0f;
-    for (int i = 0; i < kNSymD; ++i) {
-        const float cs = (float)jb->sym[i];
-        // wsprd.c:343, all double: TWOPIDT*(f0 + (drift/2.0)*(i - 81.0)/81.0 + (cs - 1.5)*375.0/256.0)
-        const double arg = (double)f0 + ((double)drift / 2.0) * ((double)(float)i - 81.0) / 81.0
-                           + ((double)cs - 1.5) * 375.0 / 256.0;
-        const float dphi = (float)(kTwoPiDt * arg);
-#pragma unroll 8
-        for (int j = 0; j < kSps; ++j) {
-            out[(size_t)(i * kSps + j) * pitch] = phi;
-            phi = phi + dphi;
-        }
-    }
+__device__ __forceinline__ float dphi_of_symbol(float f0, float drift, int i, unsigned cs) {
+    // wsprd.c:343, all double: TWOPIDT*(f0 + (drift/2.0)*(i - 81.0)/81.0 + (cs - 1.5)*375.0/256.0)
+    const double arg = (double)f0 + ((double)drift / 2.0) * ((double)(float)i - 81.0) / 81.0
+                       + ((double)(float)cs - 1.5) * 375.0 / 256.0;
+    return (float)(kTwoPiDt * arg);
 }
 
-// 64 jobs x 64 samples per workgroup: phases arrive job-fastest, are transposed through LDS,
-// then each wave owns one job row at a time (sample-fastest, coalesced)
+// lane = job: the run decomposition of the serial float phase walk.  The channel symbols are staged
+// through LDS first so that the serial part touches no global memory but its own stores.
+__global__ __launch_bounds__(64)
+void sub_runs_kernel(const SubJob* __restrict__ jobs, int njobs, PhaseTable* __restrict__ tables) {
+    __shared__ unsigned char sym[64][kNSymD + 2];
+    const int lane = threadIdx.x, job0 = blockIdx.x * 64;
+    for (int q = 0; q < 64 && job0 + q < njobs; ++q)
+        for (int i = lane; i < kNSymD; i += 64) sym[q][i] = jobs[job0 + q].sym[i];
+    __syncthreads();
+    const int job = job0 + lane;
+    if (job >= njobs) return;
+    PhaseTable& tb = tables[job];
+    const float f0 = jobs[job].f0, drift = jobs[job].drift;
+    const unsigned char* cs = sym[lane];
+    for (int i = 0; i < kNSymD; ++i) tb.dphi[i] = dphi_of_symbol(f0, drift, i, cs[i]);
+    const int nr = phase_runs_build([&](int i) { return dphi_of_symbol(f0, drift, i, cs[i]); }, kNSymD, kSps, tb.runs,
+                                    kPhaseMaxRuns, tb.first_run, tb.sym_phi);
+    if (nr < 0) tb.first_run[0] = 0xffffu;
+}
+
+// One workgroup walks kSymPerWg symbols (256 samples each) of one job.  All lanes of a wave sit in the
+// same symbol, so the symbol's few runs are fetched with wave-uniform (scalar) loads and every lane
+// keeps the last one that starts at or before its sample.
+constexpr int kSymPerWg = 6;
+static_assert(kNSymD % kSymPerWg == 0, "symbols per workgroup must divide 162");
 __global__ __launch_bounds__(256)
 void sub_ref_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                    const SubJob* __restrict__ jobs, int njobs, const float* __restrict__ phiT,
+                    const SubJob* __restrict__ jobs, const PhaseTable* __restrict__ tables,
                     float* __restrict__ perjob) {
-    __shared__ float tile[64][65];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const size_t pitch = jobs_padded(njobs);
-    for (int r = wave; r < 64; r += 4) tile[r][lane] = phiT[(size_t)(n0 + r) * pitch + j0 + lane];
-    __syncthreads();
-    for (int q = wave; q < 64; q += 4) {
-        const int jobi = j0 + q;
-        if (jobi >= njobs) break;
-        const SubJob* job = jobs + jobi;
-        const int n = n0 + lane;
-        float2* __restrict__ ref = reinterpret_cast<float2*>(perjob + (size_t)jobi * kSubPerJob);
-        float2* __restrict__ cc = ref + kSigLen;
+    const int jobi = blockIdx.y, j = threadIdx.x;
+    const SubJob* job = jobs + jobi;
+    const PhaseTable& tb = tables[jobi];
+    const bool dense = tb.first_run[0] == 0xffffu;
+    const int shift = job->shift;
+    const float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
+    float2* __restrict__ ref = reinterpret_cast<float2*>(perjob + (size_t)jobi * kSubPerJob);
+    float2* __restrict__ cc = ref + kSigLen;
+#pragma unroll 1
+    for (int u = 0; u < kSymPerWg; ++u) {
+        const int sym = blockIdx.x * kSymPerWg + u;
+        const int n = sym * kSps + j;
+        float phi;
+        if (!dense) {
+            const int r0 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym]);
+            const int r1 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym + 1]);
+            PhaseRun pick = tb.runs[r0];
+            for (int r = r0 + 1; r < r1; ++r) {
+                const PhaseRun c = tb.runs[r];
+                if (c.start <= n) pick = c;
+            }
+            phi = phase_of(pick, n - pick.start);
+        } else {
+            phi = phase_from_symbol(tb.sym_phi[sym], tb.dphi[sym], j);
+        }
         float sr, cr;
-        glibc_sincosf_pair(tile[lane][q], &sr, &cr);
+        glibc_sincosf_pair(phi, &sr, &cr);
         ref[n] = make_float2(cr, sr);
-        const int k = job->shift + n;
+        const int k = shift + n;
         float a = 0.0f, b = 0.0f;
         if (k > 0 && k < np) {
-            const float x = dI[(size_t)job->seg * kIqStride + k], y = dQ[(size_t)job->seg * kIqStride + k];
+            const float x = xi[k], y = xq[k];
             const float p1 = x * cr, p2 = y * sr, p3 = y * cr, p4 = x * sr;
             a = p1 + p2;                  // Re{s conj(r)}
             b = p3 - p4;                  // Im{s conj(r)}
@@ -180,17 +207,16 @@ void normalise_kernel(float* __restrict__ dI, float* __restrict__ dQ, const int*
 }
 }  // namespace
 
-// scratch floats needed for njobs jobs (transposed phase table + per-job r and s*conj(r))
-size_t subtract_scratch_floats(int njobs) { return (size_t)kSigLen * jobs_padded(njobs) + (size_t)njobs * kSubPerJob; }
+// scratch floats needed for njobs jobs (per job: r and s*conj(r), then the phase-run tables)
+size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kSubPerJob + kTableFloats); }
 
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
                      float* scratch, const DeviceTables& t, hipStream_t st) {
     if (njobs <= 0) return;
-    float* phiT = scratch;
-    float* perjob = scratch + (size_t)kSigLen * jobs_padded(njobs);
-    hipLaunchKernelGGL(sub_phase_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, phiT);
-    hipLaunchKernelGGL(sub_ref_kernel, dim3(kSigLen / 64, (njobs + 63) / 64), dim3(256), 0, st, dI, dQ, samples, jobs,
-                       njobs, phiT, perjob);
+    float* perjob = scratch;
+    PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch + (size_t)njobs * kSubPerJob);
+    hipLaunchKernelGGL(sub_runs_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, tables);
+    hipLaunchKernelGGL(sub_ref_kernel, dim3(kNSymD / kSymPerWg, njobs), dim3(256), 0, st, dI, dQ, samples, jobs, tables, perjob);
     hipLaunchKernelGGL(sub_filter_kernel, dim3((kSigLen + kFirOut - 1) / kFirOut, njobs), dim3(kFirThreads), 0, st,
                        dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
 }

@@ -1,0 +1,31 @@
+// Test helper: the exact jump-ahead of the float phase accumulator (csrc/kernels/phase_runs.h, used by
+// the GPU subtraction) compiled for the host, next to the plain serial walk of wsprd.c:340-351.
+#include <vector>
+#include "../../rtlsdr-wsprd_amd/csrc/kernels/phase_runs.h"
+
+// dphi: nsym floats.  Returns the number of runs (or -1), the number of samples whose reconstructed phase
+// differs from the serial walk in *mismatches (bit compare), and the walk itself in phi_out if not null.
+// max_runs <= 0: the product's table size.  When the table overflows the per-symbol fallback is checked.
+extern "C" int phase_runs_check(const float* dphi, int nsym, int sps_log2, long* mismatches, float* phi_out, int max_runs) {
+    const int sps = 1 << sps_log2;
+    if (max_runs <= 0) max_runs = wspr::kPhaseMaxRuns;
+    std::vector<wspr::PhaseRun> runs(max_runs);
+    std::vector<uint16_t> first(nsym + 1);
+    std::vector<float> sym_phi(nsym);
+    const int nr = wspr::phase_runs_build([&](int i) { return dphi[i]; }, nsym, sps, runs.data(), max_runs,
+                                          first.data(), sym_phi.data());
+    long bad = 0;
+    volatile float phi = 0.0f;                 // volatile: one rounded float addition per step, as compiled in the reference
+    for (int i = 0; i < nsym; ++i)
+        for (int j = 0; j < sps; ++j) {
+            const int n = i * sps + j;
+            const float ref = phi;
+            if (phi_out) phi_out[n] = ref;
+            const float got = nr >= 0 ? wspr::phase_at(runs.data(), first.data(), sps_log2, n)
+                                      : wspr::phase_from_symbol(sym_phi[i], dphi[i], j);
+            if (wspr::pr_bits(got) != wspr::pr_bits(ref)) ++bad;
+            phi = ref + dphi[i];
+        }
+    *mismatches = bad;
+    return nr;
+}
