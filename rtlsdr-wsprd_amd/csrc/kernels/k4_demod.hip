@@ -343,9 +343,7 @@ void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restr
 // each has ONE phasor table; the winning hypothesis' tone amplitudes are exactly
 // what mode 2 recomputes at (best freq, best lag), so the first soft-symbol vector
 // comes out of the same pass.  lane = (symbol, frequency).
-constexpr int kFreqSyms = 18;          // 18 x 5 = 90 of 128 lanes; 40 KB tables + 37 KB tile -> 2 WGs per CU
 constexpr int kNFreq = 5;
-constexpr int kFreqThreads = 256;     // all of them stage the tables and samples; 90 of them compute
 
 __global__ __launch_bounds__(64)
 void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin,
@@ -372,53 +370,60 @@ void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restri
     }
 }
 
-__global__ __launch_bounds__(kFreqThreads)
+// Workgroup = (candidate, frequency hypothesis), lane = symbol: 162 of 192 lanes run one serial
+// 256-sample tone correlation each.  The hypothesis' phasor table (8 KB) sits in LDS and is read
+// as a broadcast; the samples stream through LDS in chunks of 32 per symbol (coalesced 128-byte row
+// segments from HBM/L2, transposed so that lane = symbol reads conflict-free), the next chunk in
+// flight in registers while the current one is consumed.
+constexpr int kFsThreads = 192;
+constexpr int kFsChunk = 32;
+constexpr int kFsPerThread = kNSymD * kFsChunk / kFsThreads;      // 27 samples staged per thread and chunk
+static_assert(kNSymD * kFsChunk % kFsThreads == 0, "chunk must split evenly over the workgroup");
+
+__global__ __launch_bounds__(kFsThreads)
 void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                       const FineState* __restrict__ items, const int* __restrict__ item_list,
                       const float* __restrict__ tabs, float4* __restrict__ pw_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int slot = blockIdx.y, tid = threadIdx.x;
+    __shared__ float4 tab[2 * kSps];                                 // (c0..c3), (s0..s3) per sample
+    __shared__ float2 tile[kNSymD][kFsChunk + 1];
+    const int slot = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
     const FineState st = items[item_list[slot]];
-    const int i0 = blockIdx.x * kFreqSyms;
-    float4* tab = reinterpret_cast<float4*>(smem);                         // [5][256][2]
-    float2* tile = reinterpret_cast<float2*>(smem + kNFreq * 8192);        // [18][257]
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * 512;
-    // prologue: issue the loads in batches so their latencies overlap
-    {
-        float4 v[10];                                       // 5 * 512 float4 = 10 per thread
-#pragma unroll
-        for (int u = 0; u < 10; ++u) v[u] = gt[u * kFreqThreads + tid];
-#pragma unroll
-        for (int u = 0; u < 10; ++u) tab[u * kFreqThreads + tid] = v[u];
-    }
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps);
+    for (int e = tid; e < 2 * kSps; e += kFsThreads) tab[e] = gt[e];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int kbase = st.shift + kSps * i0;
+
+    float2 nxt[kFsPerThread];
+    auto fetch = [&](int c) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {                           // 18 * 256 samples = 2 x 9 per thread
-        float2 v[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int k = kbase + (h * 9 + u) * kFreqThreads + tid;
+        for (int u = 0; u < kFsPerThread; ++u) {
+            const int e = u * kFsThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
+            const int k = st.shift + kSps * row + kFsChunk * c + col;
             const bool ok = (k > 0) && (k < np);
-            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+            nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
         }
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int e = (h * 9 + u) * kFreqThreads + tid;
-            tile[(e >> 8) * 257 + (e & 255)] = v[u];
-        }
-    }
-    __syncthreads();
-    if (tid >= kFreqSyms * kNFreq) return;
-    const int il = tid / kNFreq, f = tid - il * kNFreq;
-    const float4* __restrict__ tb = tab + f * 512;
-    const float2* __restrict__ td = tile + il * 257;
+    };
+    fetch(0);
     ToneAcc acc;
     acc.clear();
+    for (int c = 0; c < kSps / kFsChunk; ++c) {
+        __syncthreads();                                             // the previous chunk has been consumed
+#pragma unroll
+        for (int u = 0; u < kFsPerThread; ++u) {
+            const int e = u * kFsThreads + tid;
+            tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
+        }
+        __syncthreads();
+        if (c + 1 < kSps / kFsChunk) fetch(c + 1);
+        if (tid < kNSymD) {
 #pragma unroll 8
-    for (int j = 0; j < kSps; ++j) acc.step(td[j], tb[2 * j], tb[2 * j + 1]);
-    pw_out[((size_t)slot * kNFreq + f) * kNSymD + i0 + il] = acc.amplitudes();
+            for (int jj = 0; jj < kFsChunk; ++jj) {
+                const int j = kFsChunk * c + jj;
+                acc.step(tile[tid][jj], tab[2 * j], tab[2 * j + 1]);
+            }
+        }
+    }
+    if (tid < kNSymD) pw_out[((size_t)slot * kNFreq + f) * kNSymD + tid] = acc.amplitudes();
 }
 
 // one wave per candidate: lanes 0..4 fold one frequency hypothesis each (162 symbols in
@@ -559,12 +564,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                                      float* rms_out, const DeviceTables& t, hipStream_t st) {
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-        constexpr size_t lds = kNFreq * 8192 + kFreqSyms * 257 * sizeof(float2);        // 77 KB
-        // 77 KB of dynamic LDS needs an explicit opt-in (default limit 64 KB)
-        static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(freq_tile_kernel),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)opt_in;
-        hipLaunchKernelGGL(freq_tile_kernel, dim3(kNSymD / kFreqSyms, n_shared), dim3(kFreqThreads), lds, st, dI, dQ,
+        hipLaunchKernelGGL(freq_tile_kernel, dim3(kNFreq, n_shared), dim3(kFsThreads), 0, st, dI, dQ,
                            samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
                            reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
