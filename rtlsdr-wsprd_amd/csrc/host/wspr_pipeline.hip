@@ -164,12 +164,25 @@ struct Context::Impl {
     size_t hash_arena_segs = 0;
     double t_ms[16] = {0};           // stage times (ms) and Fano statistics of the last batch
     std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0};
+    bool blocking = false;
+    hipEvent_t ev_sync = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 // CPUs this process may actually use: hardware threads capped by the cgroup CPU quota
 // (a container on a shared GPU node typically owns a slice; running more runnable threads
 // than the quota gets the whole process throttled)
+static int usable_cpus();
+// CPUs this process may count on: WSPR_HOST_THREADS (a rank's share when several ranks share a host),
+// else the cgroup quota / affinity mask
+static int host_cpus() {
+    static const int n = [] {
+        int v = usable_cpus();
+        if (const char* e = getenv("WSPR_HOST_THREADS")) v = atoi(e);
+        return std::max(1, v);
+    }();
+    return n;
+}
 static int usable_cpus() {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
@@ -196,8 +209,14 @@ Context::Context(int nslots) : d(new Impl) {
         throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
     HIP_OK(hipGetDevice(&d->device));
     HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreate(&d->ev[0]));
-    HIP_OK(hipEventCreate(&d->ev[1]));
+    // WSPR_BLOCKING_SYNC=1: waiting host threads sleep instead of spinning (for hosts with fewer CPUs
+    // than slot threads, e.g. 8 ranks sharing a small CPU quota)
+    const char* bs = getenv("WSPR_BLOCKING_SYNC");
+    d->blocking = bs ? atoi(bs) != 0 : host_cpus() < 4;
+    const unsigned evflags = d->blocking ? hipEventBlockingSync : hipEventDefault;
+    HIP_OK(hipEventCreateWithFlags(&d->ev[0], evflags));
+    HIP_OK(hipEventCreateWithFlags(&d->ev[1], evflags));
+    HIP_OK(hipEventCreateWithFlags(&d->ev_sync, evflags | hipEventDisableTiming));
 
     // constant tables, computed with the host libm exactly as the reference does
     std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
@@ -239,8 +258,7 @@ Context::Context(int nslots) : d(new Impl) {
     d->tab.min_snr = powf(10.0, -8.0 / 10.0);                                        // wsprd.c:590
     d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
 
-    int nthreads = usable_cpus();
-    if (const char* e = getenv("WSPR_HOST_THREADS")) nthreads = atoi(e);
+    int nthreads = host_cpus();
     nthreads = std::max(1, std::min(nthreads, 256) / std::max(1, nslots));   // the slots share the host's CPUs
     d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
     d->bigpool.reset(new Pool(nthreads - 1));
@@ -251,9 +269,12 @@ Context::~Context() {}
 // Number of concurrent pipelines ("slots"): each owns a HIP stream, buffers and host pools and
 // decodes its own share of a batch, so that one slot's host phases (Fano, bookkeeping, copies)
 // overlap the other slots' kernels.
+// Three slots need about three CPUs for their driver threads (kernel launches are the host's main
+// cost); with fewer, extra slots only take each other's time slices (2 CPUs: 2 slots 155 k, 3 slots
+// 128 k segments/s on config 2).
 int Context::slots() {
     static const int n = [] {
-        int v = 3;
+        int v = std::min(3, host_cpus());
         if (const char* e = getenv("WSPR_SLOTS")) v = atoi(e);
         return std::max(1, std::min(v, 8));
     }();
@@ -308,7 +329,12 @@ void Context::store_host(float* I, float* Q, int nseg, int samples, size_t strid
 }
 void Context::sync() {
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(d->stream));
+    if (d->blocking) {
+        HIP_OK(hipEventRecord(d->ev_sync, d->stream));
+        HIP_OK(hipEventSynchronize(d->ev_sync));
+    } else {
+        HIP_OK(hipStreamSynchronize(d->stream));
+    }
 }
 
 float* Context::ps_buffer(int nseg) {
