@@ -104,39 +104,46 @@ WSPR_PR_HD int phase_batch(float phi, float d, int steps, int32_t* m_out, int32_
     return n > steps ? steps : n;
 }
 
+// One step of the decomposition: the sample at `pos` has phase `phi`; emits the run that starts
+// there (covering n + 1 samples, n <= limit) and advances phi to the phase of the sample after it.
+WSPR_PR_HD int phase_next_run(float& phi, float d, int pos, int limit, PhaseRun& r) {
+    int32_t m = 0, q = 0, e = 0;
+    const int n = phase_batch(phi, d, limit, &m, &q, &e);
+    r.start = pos;
+    if (n > 0) { r.m0 = m; r.q = q; r.e = e; }
+    else       { r.m0 = (int32_t)pr_bits(phi); r.q = 0; r.e = kPhaseRawBits; }
+    const float last = n > 0 ? phase_of(r, n) : phi;
+    phi = last + d;
+    return n;
+}
+
 // Decompose the walk of one signal: nsym symbols of sps samples, increment dphi[i] during symbol i,
 // phi = 0 before the first sample.  runs[] receives the runs (ascending start), first_run[i] the index
 // of the run containing sample i*sps (nsym + 1 entries, the last = number of runs).  Returns the
 // number of runs, or -1 if max_runs is too small; sym_phi[i] (optional) = phase of sample i*sps, filled
 // in either case, so that a caller can still evaluate an overflowing walk symbol by symbol
-// (phase_from_symbol).
+// (phase_from_symbol).  Written as one flat loop (a run per trip, symbol changes folded in) so that
+// SIMT lanes working on different signals stay in step.
 template <class DphiOf>
 WSPR_PR_HD int phase_runs_build(const DphiOf& dphi_of, int nsym, int sps, PhaseRun* runs, int max_runs,
                                 uint16_t* first_run, float* sym_phi = nullptr) {
-    float phi = 0.0f;
-    int nr = 0;
+    float phi = 0.0f, d = 0.0f;
+    int nr = 0, i = -1, left = 0, pos = 0;
     bool full = false;
-    for (int i = 0; i < nsym; ++i) {
-        const float d = dphi_of(i);
-        if (sym_phi) sym_phi[i] = phi;
-        if (!full) first_run[i] = (uint16_t)nr;
-        int pos = i * sps, left = sps;          // samples of this symbol still to be assigned a phase
-        while (left > 0) {
-            // the sample at `pos` has phase phi; how many further samples follow the linear rule?
-            int32_t m = 0, q = 0, e = 0;
-            const int n = phase_batch(phi, d, left - 1, &m, &q, &e);
-            if (nr >= max_runs) full = true;
-            PhaseRun r;
-            r.start = pos;
-            if (n > 0) { r.m0 = m; r.q = q; r.e = e; }
-            else       { r.m0 = (int32_t)pr_bits(phi); r.q = 0; r.e = kPhaseRawBits; }
-            if (!full) runs[nr++] = r;
-            // the run covers samples pos .. pos + n; the phase after it is one more addition
-            const float last = n > 0 ? phase_of(r, n) : phi;
-            phi = last + d;
-            pos += n + 1;
-            left -= n + 1;
+    for (;;) {
+        if (left == 0) {
+            if (++i == nsym) break;
+            d = dphi_of(i);
+            if (sym_phi) sym_phi[i] = phi;
+            if (!full) first_run[i] = (uint16_t)nr;
+            left = sps;
         }
+        PhaseRun r;
+        const int n = phase_next_run(phi, d, pos, left - 1, r);
+        if (nr >= max_runs) full = true;
+        if (!full) runs[nr++] = r;
+        pos += n + 1;
+        left -= n + 1;
     }
     if (full) return -1;
     first_run[nsym] = (uint16_t)nr;
