@@ -148,7 +148,9 @@ __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], con
         const int col = bin - kPsBin0;
         if (col >= 0 && col < kPsBins) {
             const v2 e = x[r] * x[r];
-            row[col] = e.x + e.y;
+            // streaming store: the spectrogram is far larger than the L2s and is next read by another
+            // kernel (measured: K1 unchanged, the time average that follows 185 -> 143 us per 1024 segments)
+            __builtin_nontemporal_store(e.x + e.y, row + col);
         }
     }
 }

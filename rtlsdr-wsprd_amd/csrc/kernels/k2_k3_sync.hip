@@ -27,20 +27,21 @@ void time_average_kernel(const float* __restrict__ ps, const int* __restrict__ s
     const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
     const int col = 4 * (blockIdx.x * 64 + threadIdx.x);          // 4 bins (16 B) per lane
     if (col >= kPsBins) return;                                     // columns 417..431 of a row are padding
-    const float4* __restrict__ P = reinterpret_cast<const float4*>(ps + (size_t)seg * kMaxBlocks * kPsStride + col);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* __restrict__ P = reinterpret_cast<const f4*>(ps + (size_t)seg * kMaxBlocks * kPsStride + col);
     constexpr int kRow4 = kPsStride / 4;
     // four independent serial chains per lane; batch the loads ahead of the adds
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     constexpr int kUnroll = 8;
     int t = 0;
     for (; t + kUnroll <= blocks; t += kUnroll) {
-        float4 v[kUnroll];
+        f4 v[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) v[u] = P[(size_t)(t + u) * kRow4];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    for (; t < blocks; ++t) { const float4 v = P[(size_t)t * kRow4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    for (; t < blocks; ++t) { const f4 v = P[(size_t)t * kRow4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     *reinterpret_cast<float4*>(psavg + (size_t)seg * kPsStride + col) = acc;
 }
 
