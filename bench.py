@@ -285,6 +285,18 @@ def main():
                                    "bytes_per_launch": STAGE_BYTES * nseg,
                                    "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
                                    "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
+        # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
+        if args.config != 5:
+            n_copy = 1 << 28
+            src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
+            dst = torch.empty_like(src)
+            torch.cuda.synchronize()
+            w.lib().wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
+            t0 = time.perf_counter()
+            w.lib().wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
+            roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
+            del src, dst
         if args.config == 5:
             kms = (C.c_double * 1)()
             w.lib().wspr_bench_decimate(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 3, C.addressof(kms))
