@@ -159,10 +159,12 @@ int wspr_stage_fft_bank(const float *idat, const float *qdat, int nseg, int samp
 int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int samples,
                           size_t seg_stride, int coarse, int maxdrift, struct cand *cand_out,
                           int *npk_out, float *noise_out, float *smspec_out);
-/* Timing of the stages of the most recent batch call, milliseconds (HIP events on
- * the library's stream / host clock). Order: fft+sync stage, host bookkeeping, (unused), fine
- * sync + demod, subtract, host Fano, total, then counts: Fano calls, Fano time-outs, Fano
- * cycles. Returns the number of values written. */
+/* Timing of the stages of the most recent batch call, milliseconds (HIP events on the library's
+ * streams / host clock, summed over the slots).  Order: [0] FFT+sync stage, [1] host bookkeeping,
+ * [2] device Fano tail (K6), [3] fine sync + demod, [4] subtract, [5] host Fano, [6] total wall time,
+ * then counts: [7] Fano calls, [8] Fano time-outs, [9] Fano cycles, [10] candidates refined, [11] GPU
+ * waves, [12] Fano attempts left to the device tail, [13] segments decoded a second time.  Returns
+ * the number of values written (<= capacity). */
 int wspr_last_timings(double *ms, int capacity);
 /* Times `iters` passes of the FFT+sync stage (K1,K2,K3) on resident data with HIP events on the
  * launch stream.  ms must hold 8 doubles: ms[0] = K1 (sum over the segment chunks of a pass),
