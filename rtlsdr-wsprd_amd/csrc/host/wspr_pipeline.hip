@@ -588,7 +588,19 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
         // it decodes AND is subtracted.  Each segment therefore submits a window of `win` consecutive
         // candidates per wave; the window is cut at the first subtraction (later results are dropped
         // and recomputed on the new residual) and doubles, up to 64, after a window with none.
+        // The coarse sync value predicts which candidates can decode at all (of the candidates that
+        // decode, 0.1 % have a coarse sync below 0.12; most noise peaks are below it): a window also
+        // runs through all the unlikely candidates up to and including the next likely one, so that a
+        // segment's noise peaks cost one wave, not a doubling series of them.  Speculation is always
+        // validated, so the prediction only affects how much work is wasted, never the result.
+        constexpr float kLikelySync = 0.12f;
         std::vector<int> next_cand(nseg, 0), win(nseg, 1);
+        auto window_of = [&](int s) {
+            const int n = std::min(npk[s], kMaxCand), lo = next_cand[s];
+            int w = 0;
+            while (lo + w < n && w < kMaxCand && !(cand[(size_t)s * kMaxCand + lo + w].sync >= kLikelySync)) ++w;
+            return std::max(win[s], std::min(w + 1, n - lo));
+        };
 
         for (;;) {
             // ---- build the wave ------------------------------------------------
@@ -596,18 +608,20 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
             // its phasor tables, so the wave size is bounded: speculative windows shrink first, and
             // whatever still does not fit waits for the next wave.
             constexpr int kMaxWave = 65536;
+            std::vector<int> weff(nseg, 0);
             if (lockstep) {
+                for (int s : active) if (!stopped[s]) weff[s] = window_of(s);
                 for (;;) {
                     long total = 0;
                     bool shrinkable = false;
                     for (int s : active) {
                         if (stopped[s]) continue;
                         const int left = std::min(npk[s], kMaxCand) - next_cand[s];
-                        total += std::max(0, std::min(left, win[s]));
-                        shrinkable |= win[s] > 1;
+                        total += std::max(0, std::min(left, weff[s]));
+                        shrinkable |= weff[s] > 1;
                     }
                     if (total <= kMaxWave || !shrinkable) break;
-                    for (int s : active) win[s] = std::max(1, win[s] / 2);
+                    for (int s : active) { weff[s] = std::max(1, weff[s] / 2); win[s] = std::min(win[s], weff[s]); }
                 }
             }
             std::vector<WaveItem> wave;
@@ -615,7 +629,7 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
                 if (stopped[s]) continue;
                 const int n = std::min(npk[s], kMaxCand);
                 const int lo = next_cand[s];
-                const int hi = lockstep ? std::min(n, lo + win[s]) : n;
+                const int hi = lockstep ? std::min(n, lo + weff[s]) : n;
                 if (hi <= lo) continue;
                 if (!wave.empty() && (int)wave.size() + (hi - lo) > kMaxWave) break;   // next wave
                 for (int j = lo; j < hi; ++j) wave.push_back(WaveItem{s, j});
