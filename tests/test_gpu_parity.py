@@ -199,6 +199,42 @@ def test_batch_decode_equals_oracle(w, synth_batch, opts):
             assert [x.message.decode() for x in got[s]] == [synth.expected_text(truth[s][0][0])]
 
 
+def test_randomised_scenes_equal_oracle(w):
+    """Forty random scenes the fixed fixtures do not cover: 0-6 signals of type 1/2/3, SNR -31..+6 dB,
+    drifts -3..+3 Hz, starts 0.2..3.8 s (part of the frame may fall off either end), carriers out to
+    +-125 Hz (beyond the +-110 Hz candidate window), two signals a few Hz apart, a strong CW carrier, and
+    a segment of plain noise.  Every spot field must equal the oracle's (SNR within the stated 0.1 dB)."""
+    rng = np.random.default_rng(int(os.environ.get("WSPR_SCENE_SEED", "20260928")))
+    sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+    t23 = ["PJ4/K1ABC 37", "K1ABC/7 33", "<PJ4/K1ABC> FK52UD 37"]
+    Is, Qs = [], []
+    for scene in range(int(os.environ.get("WSPR_SCENES", "40"))):      # (a longer soak: WSPR_SCENES=400)
+        I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
+        nsig = 0 if scene == 0 else int(rng.integers(1, 7))
+        base = rng.uniform(-125, 125, nsig)
+        if nsig >= 2 and scene % 5 == 0:
+            base[1] = base[0] + rng.uniform(1.0, 4.0)               # near-collision
+        for k in range(nsig):
+            msg = t23[int(rng.integers(0, 3))] if rng.random() < 0.2 else synth.message_for(int(rng.integers(0, 1 << 20)))
+            amp = 10.0 ** (rng.uniform(-31, 6) / 20.0)
+            si, sq = synth.tone_signal(symf(msg), base[k], rng.uniform(0.2, 3.8), amp, drift=float(rng.integers(-3, 4)))
+            I += si; Q += sq
+        if scene % 7 == 3:                                            # unmodulated carrier
+            ph = 2 * np.pi * rng.uniform(-100, 100) / 375.0 * np.arange(NS)
+            I += 3.0 * np.cos(ph); Q += 3.0 * np.sin(ph)
+        a, b = synth.normalise(I.astype(np.float32), Q.astype(np.float32))
+        Is.append(a); Qs.append(b)
+    I = np.stack(Is); Q = np.stack(Qs)
+    got = w.wspr_decode_batch(I, Q, w.default_options())
+    total = 0
+    for s in range(I.shape[0]):
+        ref, _, _ = ol.decode(I[s], Q[s], NS)
+        assert [_spot_tuple(x) for x in got[s]] == [_spot_tuple(x) for x in ref], s
+        assert all(abs(a.snr - b.snr) < 1e-4 for a, b in zip(got[s], ref))
+        total += len(ref)
+    assert total > 40 and len(got[0]) == 0
+
+
 def test_empty_and_degenerate_inputs(w):
     z = np.zeros((2, NS), np.float32)
     assert w.wspr_decode_batch(z, z) == [[], []]
