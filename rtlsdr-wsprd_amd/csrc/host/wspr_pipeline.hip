@@ -209,10 +209,11 @@ Context::Context(int nslots) : d(new Impl) {
         throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
     HIP_OK(hipGetDevice(&d->device));
     HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    // WSPR_BLOCKING_SYNC=1: waiting host threads sleep instead of spinning (for hosts with fewer CPUs
-    // than slot threads, e.g. 8 ranks sharing a small CPU quota)
+    // Waiting host threads sleep on blocking events instead of spinning: never slower here (184 k vs
+    // 180 k segments/s with 16 CPUs, 129 k vs 123 k with 2) and it leaves the CPUs to the Fano pools and
+    // to other ranks.  WSPR_BLOCKING_SYNC=0 restores spinning.
     const char* bs = getenv("WSPR_BLOCKING_SYNC");
-    d->blocking = bs ? atoi(bs) != 0 : host_cpus() < 4;
+    d->blocking = bs ? atoi(bs) != 0 : true;
     const unsigned evflags = d->blocking ? hipEventBlockingSync : hipEventDefault;
     HIP_OK(hipEventCreateWithFlags(&d->ev[0], evflags));
     HIP_OK(hipEventCreateWithFlags(&d->ev[1], evflags));
