@@ -79,3 +79,19 @@ def test_product_never_references_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", w.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_reference_unit_tests_pass_against_the_product_library():
+    """the reference's own harness tests/test_wsprd.c, compiled where it lies and linked
+    against libwspr_mi355x.so instead of the reference objects (oracle/Makefile, target dropin), must
+    pass unchanged: 18 tests over character codes, call/grid packing, unpack50, interleaver, Fano
+    round trip, nhash, comparators, channel symbols and unpk_."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_wsprd_dropin")
+    if os.path.isdir("/root/reference/tests"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"], check=True)
+    if not os.path.exists(exe):
+        pytest.skip("drop-in harness not built (reference not mounted here)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "18/18 passed, 0 failed" in r.stdout
