@@ -73,6 +73,7 @@ public:
                         uint32_t cap, uint32_t* new_fill);
 
     struct Impl;
+    struct DecodeRun;               // state of one decode_core() call (wspr_pipeline.hip)
     std::unique_ptr<Impl> d;
 
 private:

@@ -501,13 +501,16 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     return 0;
 }
 
-// One full decode (all passes) of the segments in `active0`.  fast = 0: the host Fano pool runs the
-// reference's full cycle budget (exact on its own).  fast > 0: it runs `fast` cycles per bit and
-// records every attempt it could not finish in `pend` (see decode_resident).
-int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
-                         int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend) {
-    Impl& c = *d;
-    for (int s : active0) n_results[s] = 0;
+// State of one decode_core() call: the passes over a set of segments, wave by wave.
+struct Context::DecodeRun {
+    Context& ctx;
+    Context::Impl& c;
+    const int nseg, samples;
+    const decoder_options& opt;
+    decoder_results* const out;
+    const int max_results;
+    const unsigned fast;                      // host Fano budget (cycles per bit) or 0 = the reference's
+    PendingFano& pend;
 
     // tuning constants of wsprd.c:423-433
     const float minsync1 = 0.10f;
@@ -515,380 +518,426 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
     int maxdrift = 4;
     const float minrms = 52.0 * (50 / 64.0);
     const int delta = 60;
-    const unsigned maxcycles = fast ? fast : 10000u;
-    const int lagstep = opt.quickmode ? 16 : 8;
-    const int nlag0 = 256 / lagstep + 1;
-    const int njit_rest = opt.quickmode ? 0 : kMaxLags - 1;
+    const unsigned maxcycles;
+    const int lagstep, nlag0, njit_rest;
     const FanoMetrics& met = default_metrics();
 
-    // per-segment hash memory: one zeroed table pair per segment, reused across batches
-    const size_t per_seg = (size_t)kHashSlots * (kHashWidth + kLocWidth);
-    if (c.hash_arena_segs < (size_t)nseg) {
-        free(c.hash_arena);
-        c.hash_arena = static_cast<char*>(calloc((size_t)nseg, per_seg));
-        if (!c.hash_arena) throw std::runtime_error("out of host memory for hash tables");
-        c.hash_arena_segs = (size_t)nseg;
-    }
-    auto hashtab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg; };
-    auto loctab_of = [&](int s) { return c.hash_arena + (size_t)s * per_seg + (size_t)kHashSlots * kHashWidth; };
-
-    // Callsign hash memory across calls (wsprd.c:481-494): hashtable.txt in the working directory.
-    // It makes the result depend on the order of calls, so it is honoured for single-segment calls
-    // (the daemon's one decode per two minutes) and ignored for batches (SURVEY §8e caveat, §8f3).
-    const bool persist = opt.usehashtable && nseg == 1;
-    if (persist) {
-        if (FILE* fh = fopen("hashtable.txt", "r+")) {
-            char line[80], hcall[13], hgrid[5];
-            int nh;
-            while (fgets(line, sizeof line, fh) != nullptr) {
-                hgrid[0] = hcall[0] = '\0';
-                if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
-                if (nh >= 0 && nh < kHashSlots) {
-                    snprintf(hashtab_of(0) + nh * kHashWidth, kHashWidth, "%s", hcall);
-                    if (strlen(hgrid) > 0) snprintf(loctab_of(0) + nh * kLocWidth, kLocWidth, "%s", hgrid);
-                }
-            }
-            fclose(fh);
-        }
-    }
-
-    std::vector<SegBook> book(nseg);
+    // per-segment state across passes
+    std::vector<SegBook> book;
     std::vector<int> npk;
     std::vector<DevCand> cand;
-    std::vector<int> active = active0;
+    // per-pass state
+    int ipass = 0;
+    bool lockstep = false;
+    std::vector<char> stopped;
+    std::vector<int> next_cand, win;
+    // callsign hash memory: one zeroed table pair per segment, reused across batches
+    const size_t per_seg = (size_t)kHashSlots * (kHashWidth + kLocWidth);
+    const bool persist;                       // hashtable.txt (single-segment calls only)
+    // buffers of the current wave
+    int n_shared = 0, n_own = 0;
+    FineState *h_items = nullptr, *d_items = nullptr;
+    int *h_lists = nullptr, *d_lists = nullptr;
+    float *d_tabs = nullptr, *d_pw = nullptr, *d_sync = nullptr, *d_rms = nullptr, *h_sync = nullptr, *h_rms = nullptr;
+    unsigned char *d_sym = nullptr, *h_sym = nullptr;
 
-    for (int ipass = 0; ipass < opt.npasses; ++ipass) {
-        if (ipass == 1) {                                      // wsprd.c:522-523
-            std::vector<int> keep;
-            for (int s : active) if (book[s].uniques > 0) keep.push_back(s);
-            active.swap(keep);
-        }
-        if (active.empty()) break;
-        if (ipass < 2) { maxdrift = 4; minsync2 = 0.12f; }
-        if (ipass == 2) { maxdrift = 0; minsync2 = 0.10f; }
-
-        // ---- FFT bank, peaks, coarse sync for the active segments -----------
-        const int nact = (int)active.size();
-        int* d_seglist = nullptr;
-        if (nact != nseg) {
-            int* h = static_cast<int*>(c.h_seglist.need((size_t)nact * 4));
-            memcpy(h, active.data(), (size_t)nact * 4);
-            d_seglist = static_cast<int*>(c.seglist.need((size_t)nact * 4));
-            upload(d_seglist, h, (size_t)nact * 4, c.stream);
-        }
-        {
-            Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[0]);
-            run_fft_sync(nseg, samples, maxdrift, true, d_seglist, nact, nullptr, nullptr);
-            t.stop();
-        }
-        fetch_candidates(nseg, npk, cand);
-
-        const bool lockstep = opt.subtraction && ipass == 0;
-        std::vector<char> stopped(nseg, 0);
-        // Speculative windows (lockstep passes): a candidate only invalidates the ones after it when
-        // it decodes AND is subtracted.  Each segment therefore submits a window of `win` consecutive
-        // candidates per wave; the window is cut at the first subtraction (later results are dropped
-        // and recomputed on the new residual) and doubles, up to 64, after a window with none.
-        // The coarse sync value predicts which candidates can decode at all (of the candidates that
-        // decode, 0.1 % have a coarse sync below 0.12; most noise peaks are below it): a window also
-        // runs through all the unlikely candidates up to and including the next likely one, so that a
-        // segment's noise peaks cost one wave, not a doubling series of them.  Speculation is always
-        // validated, so the prediction only affects how much work is wasted, never the result.
-        constexpr float kLikelySync = 0.12f;
-        std::vector<int> next_cand(nseg, 0), win(nseg, 1);
-        auto window_of = [&](int s) {
-            const int n = std::min(npk[s], kMaxCand), lo = next_cand[s];
-            int w = 0;
-            while (lo + w < n && w < kMaxCand && !(cand[(size_t)s * kMaxCand + lo + w].sync >= kLikelySync)) ++w;
-            return std::max(win[s], std::min(w + 1, n - lo));
-        };
-
-        for (;;) {
-            // ---- build the wave ------------------------------------------------
-            // A refined candidate holds up to ~110 KB of scratch (tone amplitudes for 43 lags) plus
-            // its phasor tables, so the wave size is bounded: speculative windows shrink first, and
-            // whatever still does not fit waits for the next wave.
-            constexpr int kMaxWave = 65536;
-            std::vector<int> weff(nseg, 0);
-            if (lockstep) {
-                for (int s : active) if (!stopped[s]) weff[s] = window_of(s);
-                for (;;) {
-                    long total = 0;
-                    bool shrinkable = false;
-                    for (int s : active) {
-                        if (stopped[s]) continue;
-                        const int left = std::min(npk[s], kMaxCand) - next_cand[s];
-                        total += std::max(0, std::min(left, weff[s]));
-                        shrinkable |= weff[s] > 1;
-                    }
-                    if (total <= kMaxWave || !shrinkable) break;
-                    for (int s : active) { weff[s] = std::max(1, weff[s] / 2); win[s] = std::min(win[s], weff[s]); }
-                }
-            }
-            std::vector<WaveItem> wave;
-            for (int s : active) {
-                if (stopped[s]) continue;
-                const int n = std::min(npk[s], kMaxCand);
-                const int lo = next_cand[s];
-                const int hi = lockstep ? std::min(n, lo + weff[s]) : n;
-                if (hi <= lo) continue;
-                if (!wave.empty() && (int)wave.size() + (hi - lo) > kMaxWave) break;   // next wave
-                for (int j = lo; j < hi; ++j) wave.push_back(WaveItem{s, j});
-                if (!lockstep) next_cand[s] = n;
-            }
-            const int nw = (int)wave.size();
-            if (nw == 0) break;
-            c.t_ms[10] += nw;
-            c.t_ms[11] += 1;
-
-            // ---- GPU: fine sync (mode 0, mode 1) and first soft-symbol attempt ---
-            FineState* h_items = static_cast<FineState*>(c.h_items.need((size_t)nw * sizeof(FineState)));
-            for (int i = 0; i < nw; ++i) {
-                const DevCand& cd = cand[(size_t)wave[i].seg * kMaxCand + wave[i].cand];
-                FineState f{};
-                f.seg = wave[i].seg; f.freq = cd.freq; f.drift = cd.drift; f.shift = cd.shift; f.sync = cd.sync;
-                f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
-                h_items[i] = f;
-            }
-            FineState* d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
-            int* h_lists = static_cast<int*>(c.h_lists.need((size_t)nw * 2 * 4));
-            int n_shared = 0, n_own = 0;
-            const size_t ntabs = plan_tables(h_items, nw, h_lists, &n_shared, &n_own);
-            int* d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
-            float* d_tabs = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)nw * 5) * 2048 * 4));
-            float* d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
-            const int nh_max = std::max(nlag0, kMaxLags);
-            float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
-            unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
-            float* d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
-            const float* wi = c.iqI.as<float>();
-            const float* wq = c.iqQ.as<float>();
-            float* h_sync = static_cast<float*>(c.h_sync.need((size_t)nw * kMaxLags * 4));
-            float* h_rms = static_cast<float*>(c.h_rms.need((size_t)nw * kMaxLags * 4));
-            unsigned char* h_sym = static_cast<unsigned char*>(c.h_sym.need((size_t)nw * kMaxLags * kNSymD));
-            {
-                Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
-                upload(d_items, h_items, (size_t)nw * sizeof(FineState), c.stream);
-                upload(d_lists, h_lists, (size_t)nw * 2 * 4, c.stream);
-                // mode 0: lag scan (tiled), mode 1: 5 frequencies, mode 2: first rung of the ladder
-                launch_phasor_tables(d_items, nw, 0, d_tabs, c.stream);
-                launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, nlag0, lagstep,
-                                   0.0f, d_tabs, d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
-                launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
-                {
-                    float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
-                    float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
-                    launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, lagstep,
-                                                    minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync, d_sym,
-                                                    d_rms, c.tab, c.stream);
-                }
-                HIP_OK(hipMemcpyAsync(h_items, d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
-                HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
-                HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
-                HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)nw * kNSymD, hipMemcpyDeviceToHost, c.stream));
-                t.stop();
-            }
-
-            // ---- host: first rung of the jitter ladder ----------------------------
-            const auto t_f0 = std::chrono::steady_clock::now();
-            // a candidate that passes the gates but does not decode costs a full time-out here
-            // (milliseconds) while a decode costs microseconds: one task per grab, all threads
-            Pool& pool0 = (nw >= 256) ? *c.bigpool : *c.pool;
-            pool0.run(nw, [&](int i) {
-                WaveItem& w = wave[i];
-                w.fine = h_items[i];
-                w.worth = w.fine.sync > minsync1;
-                w.decoded = false;
-                w.jitter = 0;
-                if (!w.worth) return;
-                if (h_sync[i] > minsync2 && h_rms[i] > minrms) {
-                    unsigned char sym[kNSymD];
-                    memcpy(sym, h_sym + (size_t)i * kNSymD, kNSymD);
-                    deinterleave162(sym);
-                    unsigned metric, maxnp;
-                    memset(w.decdata, 0, sizeof w.decdata);
-                    const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
-                    w.decoded = (nd == 0);
-                    w.rung0_pending = (nd != 0) && fast;
-                    if (!w.rung0_pending) { c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++; }
-                }
-            }, nw >= 256 ? 1 : 0);
-            c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
-
-            if (fast)
-                for (int i = 0; i < nw; ++i)
-                    if (wave[i].rung0_pending) pend.add(wave[i].seg, h_sym + (size_t)i * kNSymD);
-
-            // ---- remaining rungs, only for candidates that still need them --------
-            std::vector<int> again;
-            if (njit_rest > 0)
-                for (int i = 0; i < nw; ++i)
-                    if (wave[i].worth && !wave[i].decoded) again.push_back(i);
-            if (!again.empty()) {
-                const int na = (int)again.size();
-                FineState* h2 = static_cast<FineState*>(c.h_misc.need((size_t)na * sizeof(FineState)));
-                for (int a = 0; a < na; ++a) h2[a] = wave[again[a]].fine;
-                const size_t ntabs2 = plan_tables(h2, na, h_lists, &n_shared, &n_own);
-                d_tabs = static_cast<float*>(c.tabs.need(ntabs2 * 2048 * 4));
-                {
-                    // all 43 lags shift-63 .. shift+63 in steps of 3 (rung r of the ladder = lag index
-                    // (jitter+63)/3; index 21 repeats rung 0 and is ignored)
-                    Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
-                    upload(d_items, h2, (size_t)na * sizeof(FineState), c.stream);
-                    upload(d_lists, h_lists, (size_t)na * 2 * 4, c.stream);
-                    launch_phasor_tables(d_items, na, 2, d_tabs, c.stream);
-                    launch_demod_tiled(wi, wq, samples, d_items, na, d_lists, n_shared, d_lists + na, n_own, 2, kMaxLags, 3,
-                                       minsync1, d_tabs, d_pw, d_sync, d_sym, d_rms, c.tab, c.stream);
-                    HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
-                    HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
-                    HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * kMaxLags * kNSymD, hipMemcpyDeviceToHost, c.stream));
-                    t.stop();
-                }
-                const auto t_f1 = std::chrono::steady_clock::now();
-                // every (candidate, rung) Fano attempt is independent; the ladder keeps the
-                // FIRST success in rung order, so run them all and pick afterwards
-                struct Attempt { int ok; int pending; unsigned cycles; unsigned char data[11]; };
-                std::vector<Attempt> att((size_t)na * njit_rest);
-                std::vector<std::atomic<int>> first(na);
-                for (auto& f : first) f.store(njit_rest);
-                Pool& fpool = (na * njit_rest >= 256) ? *c.bigpool : *c.pool;
-                // rung-major order and one task per grab: a time-out costs ~810 000 decoder cycles
-                // (milliseconds) while a success costs microseconds, so costs are heavy-tailed; low
-                // rungs finish first and cancel the higher rungs of the same candidate
-                fpool.run(na * njit_rest, [&](int task) {
-                    const int r = task / na, a = task % na;
-                    const int idx = a * njit_rest + r;
-                    Attempt& at = att[idx];
-                    at.ok = 0;
-                    at.pending = 0;
-                    if (r > first[a].load()) return;           // an earlier rung already decoded
-                    const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
-                    if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
-                    unsigned char sym[kNSymD];
-                    memcpy(sym, h_sym + g * kNSymD, kNSymD);
-                    deinterleave162(sym);
-                    unsigned metric, maxnp;
-                    memset(at.data, 0, sizeof at.data);
-                    const int nd = fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles);
-                    at.pending = (nd != 0) && fast;
-                    if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
-                    if (nd == 0) {
-                        at.ok = 1;
-                        int cur = first[a].load();
-                        while (r < cur && !first[a].compare_exchange_weak(cur, r)) {}
-                    }
-                }, 1);
-                if (fast)      // unfinished attempts on rungs BEFORE the accepted one decide nothing yet
-                    for (int a = 0; a < na; ++a) {
-                        const int rmax = std::min(first[a].load(), njit_rest);
-                        for (int r = 0; r < rmax; ++r)
-                            if (att[(size_t)a * njit_rest + r].pending) {
-                                const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
-                                pend.add(wave[again[a]].seg, h_sym + g * kNSymD);
-                            }
-                    }
-                for (int a = 0; a < na; ++a) {
-                    const int r = first[a].load();
-                    if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
-                        WaveItem& w = wave[again[a]];
-                        w.decoded = true;
-                        w.jitter = c.jitter_ladder[r + 1];
-                        w.cycles = att[(size_t)a * njit_rest + r].cycles;
-                        memcpy(w.decdata, att[(size_t)a * njit_rest + r].data, 11);
-                    }
-                }
-                c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f1).count();
-            }
-
-            // ---- host bookkeeping in candidate order (wsprd.c:768-822) ------------
-            // items of one segment are contiguous in the wave and must be handled in order;
-            // different segments are independent -> one pool task per segment
-            const auto t_b0 = std::chrono::steady_clock::now();
-            std::vector<int> group_start;
-            for (int i = 0; i < nw; ++i)
-                if (i == 0 || wave[i].seg != wave[i - 1].seg) group_start.push_back(i);
-            group_start.push_back(nw);
-            const int ngroups = (int)group_start.size() - 1;
-            std::vector<SubJob> job_of(nw);
-            std::vector<char> has_job(nw, 0);
-            c.pool->run(ngroups, [&](int g) {
-              const int sg = wave[group_start[g]].seg;
-              bool cut = false;
-              for (int i = group_start[g]; i < group_start[g + 1] && !cut; ++i) {
-                WaveItem& w = wave[i];
-                const int s = w.seg;
-                if (stopped[s]) break;
-                if (lockstep) next_cand[s] = w.cand + 1;
-                DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
-                cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
-                if (!(w.worth && w.decoded)) continue;
-
-                signed char message[12] = {0};
-                for (int k = 0; k < 11; ++k) message[k] = (signed char)w.decdata[k];
-                char callsign[13] = {0}, call_loc_pow[23] = {0}, call[13] = {0}, loc[7] = {0}, pwr[3] = {0};
-                SegBook& bk = book[s];
-                const int noprint = unpack_message(message, hashtab_of(s), loctab_of(s), call_loc_pow, call, loc, pwr, callsign);
-                bk.dirty.push_back((int)nhash15(callsign, strlen(callsign), 146u));
-                if (opt.subtraction && ipass == 0 && !noprint) {
-                    SubJob jb{};
-                    if (channel_symbols(call_loc_pow, hashtab_of(s), loctab_of(s), jb.sym)) {
-                        jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
-                        job_of[i] = jb;
-                        has_job[i] = 1;
-                        cut = true;            // the IQ changes: later candidates of this window are redone
-                    } else {
-                        stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
-                        continue;
-                    }
-                }
-                if (!strcmp(loc, "A000AA")) { stopped[s] = 1; continue; }      // wsprd.c:792-793
-                bool dupe = false;
-                for (int u = 0; u < bk.uniques; ++u)
-                    if (!strcmp(callsign, bk.allcalls[u]) && fabs(w.fine.freq - bk.allfreqs[u]) < 3.0) dupe = true;
-                if (dupe || bk.uniques >= 100) continue;
-                snprintf(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], "%s", callsign);
-                bk.allfreqs[bk.uniques] = w.fine.freq;
-                bk.uniques++;
-                if (bk.uniques <= max_results) {
-                    decoder_results* o = out + (size_t)s * max_results + (bk.uniques - 1);
-                    const double dial = (double)opt.freq / 1e6;
-                    o->sync = w.fine.sync;
-                    // candidates[j].snr, wsprd.c:616, recomputed with the host libm from the
-                    // peak value so that the reported figure does not depend on ocml's log10f
-                    o->snr = 10.0 * log10f(cd.peak) - (float)26.3;
-                    o->dt = w.fine.shift * 1.0 / 375.0 - 2.0;
-                    o->freq = dial + (1500.0 + w.fine.freq) / 1e6;
-                    o->drift = w.fine.drift;
-                    o->cycles = (int)w.cycles;
-                    o->jitter = w.jitter;
-                    snprintf(o->message, sizeof o->message, "%s", call_loc_pow);
-                    snprintf(o->call, sizeof o->call, "%s", call);
-                    snprintf(o->loc, sizeof o->loc, "%s", loc);
-                    snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
-                }
-              }
-              if (lockstep) win[sg] = cut ? 1 : std::min(64, 2 * win[sg]);
-            });
-            std::vector<SubJob> jobs;
-            for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);
-            c.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b0).count();
-
-            // ---- GPU: subtract everything that decoded in this wave ------------------
-            if (!jobs.empty()) {
-                const int nj = (int)jobs.size();
-                SubJob* hj = static_cast<SubJob*>(c.h_jobs.need((size_t)nj * sizeof(SubJob)));
-                memcpy(hj, jobs.data(), (size_t)nj * sizeof(SubJob));
-                SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nj * sizeof(SubJob)));
-                float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nj) * 4));
-                Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[4]);
-                upload(dj, hj, (size_t)nj * sizeof(SubJob), c.stream);
-                launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nj, scratch, c.tab, c.stream);
-                t.stop();
-            }
+    DecodeRun(Context& ctx_, int nseg_, int samples_, const decoder_options& opt_, decoder_results* out_, int max_results_,
+              unsigned fast_, PendingFano& pend_)
+        : ctx(ctx_), c(*ctx_.d), nseg(nseg_), samples(samples_), opt(opt_), out(out_), max_results(max_results_),
+          fast(fast_), pend(pend_), maxcycles(fast_ ? fast_ : 10000u), lagstep(opt_.quickmode ? 16 : 8),
+          nlag0(256 / (opt_.quickmode ? 16 : 8) + 1), njit_rest(opt_.quickmode ? 0 : kMaxLags - 1), book(nseg_),
+          persist(opt_.usehashtable && nseg_ == 1) {
+        if (c.hash_arena_segs < (size_t)nseg) {
+            free(c.hash_arena);
+            c.hash_arena = static_cast<char*>(calloc((size_t)nseg, per_seg));
+            if (!c.hash_arena) throw std::runtime_error("out of host memory for hash tables");
+            c.hash_arena_segs = (size_t)nseg;
         }
     }
+    char* hashtab_of(int s) const { return c.hash_arena + (size_t)s * per_seg; }
+    char* loctab_of(int s) const { return c.hash_arena + (size_t)s * per_seg + (size_t)kHashSlots * kHashWidth; }
 
-    // results strongest first (wsprd.c:827; stable like glibc's merge sort)
+    void load_hash_file();
+    void save_hash_file();
+    void start_pass(int pass, const std::vector<int>& active);
+    std::vector<WaveItem> build_wave(const std::vector<int>& active);
+    void refine_and_first_rung(std::vector<WaveItem>& wave);
+    void remaining_rungs(std::vector<WaveItem>& wave);
+    std::vector<SubJob> keep_books(std::vector<WaveItem>& wave);
+    void subtract(const std::vector<SubJob>& jobs);
+    void finish(const std::vector<int>& active0, int* n_results);
+};
+
+// Callsign hash memory across calls (wsprd.c:481-494): hashtable.txt in the working directory.
+// It makes the result depend on the order of calls, so it is honoured for single-segment calls
+// (the daemon's one decode per two minutes) and ignored for batches (SURVEY 8e caveat, 8f3).
+void Context::DecodeRun::load_hash_file() {
+    if (!persist) return;
+    if (FILE* fh = fopen("hashtable.txt", "r+")) {
+        char line[80], hcall[13], hgrid[5];
+        int nh;
+        while (fgets(line, sizeof line, fh) != nullptr) {
+            hgrid[0] = hcall[0] = '\0';
+            if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
+            if (nh >= 0 && nh < kHashSlots) {
+                snprintf(hashtab_of(0) + nh * kHashWidth, kHashWidth, "%s", hcall);
+                if (strlen(hgrid) > 0) snprintf(loctab_of(0) + nh * kLocWidth, kLocWidth, "%s", hgrid);
+            }
+        }
+        fclose(fh);
+    }
+}
+
+void Context::DecodeRun::save_hash_file() {                   // wsprd.c:842-852
+    if (!persist) return;
+    if (FILE* fh = fopen("hashtable.txt", "w")) {
+        for (int i = 0; i < kHashSlots; ++i)
+            if (hashtab_of(0)[i * kHashWidth] != '\0')
+                fprintf(fh, "%5d %s %s\n", i, hashtab_of(0) + i * kHashWidth, loctab_of(0) + i * kLocWidth);
+        fclose(fh);
+    }
+    memset(hashtab_of(0), 0, per_seg);                        // the arena is reused by later batches
+}
+
+// FFT bank, peaks, coarse sync for the active segments; resets the per-pass state
+void Context::DecodeRun::start_pass(int pass, const std::vector<int>& active) {
+    ipass = pass;
+    if (ipass < 2) { maxdrift = 4; minsync2 = 0.12f; }
+    if (ipass == 2) { maxdrift = 0; minsync2 = 0.10f; }
+    const int nact = (int)active.size();
+    int* d_seglist = nullptr;
+    if (nact != nseg) {
+        int* h = static_cast<int*>(c.h_seglist.need((size_t)nact * 4));
+        memcpy(h, active.data(), (size_t)nact * 4);
+        d_seglist = static_cast<int*>(c.seglist.need((size_t)nact * 4));
+        upload(d_seglist, h, (size_t)nact * 4, c.stream);
+    }
+    {
+        Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[0]);
+        ctx.run_fft_sync(nseg, samples, maxdrift, true, d_seglist, nact, nullptr, nullptr);
+        t.stop();
+    }
+    ctx.fetch_candidates(nseg, npk, cand);
+    lockstep = opt.subtraction && ipass == 0;
+    stopped.assign(nseg, 0);
+    next_cand.assign(nseg, 0);
+    win.assign(nseg, 1);
+}
+
+// Speculative windows (lockstep passes): a candidate only invalidates the ones after it when it
+// decodes AND is subtracted.  Each segment therefore submits a window of `win` consecutive
+// candidates per wave; the window is cut at the first subtraction (later results are dropped and
+// recomputed on the new residual) and doubles, up to 64, after a window with none.
+// The coarse sync value predicts which candidates can decode at all (of the candidates that decode,
+// 0.1 % have a coarse sync below 0.12; most noise peaks are below it): a window also runs through
+// all the unlikely candidates up to and including the next likely one, so that a segment's noise
+// peaks cost one wave, not a doubling series of them.  Speculation is always validated, so the
+// prediction only affects how much work is wasted, never the result.
+std::vector<WaveItem> Context::DecodeRun::build_wave(const std::vector<int>& active) {
+    constexpr float kLikelySync = 0.12f;
+    // A refined candidate holds up to ~110 KB of scratch (tone amplitudes for 43 lags) plus its
+    // phasor tables, so the wave size is bounded: speculative windows shrink first, and whatever
+    // still does not fit waits for the next wave.
+    constexpr int kMaxWave = 65536;
+    auto window_of = [&](int s) {
+        const int n = std::min(npk[s], kMaxCand), lo = next_cand[s];
+        int w = 0;
+        while (lo + w < n && w < kMaxCand && !(cand[(size_t)s * kMaxCand + lo + w].sync >= kLikelySync)) ++w;
+        return std::max(win[s], std::min(w + 1, n - lo));
+    };
+    std::vector<int> weff(nseg, 0);
+    if (lockstep) {
+        for (int s : active) if (!stopped[s]) weff[s] = window_of(s);
+        for (;;) {
+            long total = 0;
+            bool shrinkable = false;
+            for (int s : active) {
+                if (stopped[s]) continue;
+                const int left = std::min(npk[s], kMaxCand) - next_cand[s];
+                total += std::max(0, std::min(left, weff[s]));
+                shrinkable |= weff[s] > 1;
+            }
+            if (total <= kMaxWave || !shrinkable) break;
+            for (int s : active) { weff[s] = std::max(1, weff[s] / 2); win[s] = std::min(win[s], weff[s]); }
+        }
+    }
+    std::vector<WaveItem> wave;
+    for (int s : active) {
+        if (stopped[s]) continue;
+        const int n = std::min(npk[s], kMaxCand);
+        const int lo = next_cand[s];
+        const int hi = lockstep ? std::min(n, lo + weff[s]) : n;
+        if (hi <= lo) continue;
+        if (!wave.empty() && (int)wave.size() + (hi - lo) > kMaxWave) break;   // next wave
+        for (int j = lo; j < hi; ++j) wave.push_back(WaveItem{s, j});
+        if (!lockstep) next_cand[s] = n;
+    }
+    c.t_ms[10] += (double)wave.size();
+    if (!wave.empty()) c.t_ms[11] += 1;
+    return wave;
+}
+
+// GPU: fine sync (mode 0, mode 1) and first soft-symbol attempt; host: first rung of the jitter ladder
+void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
+    const int nw = (int)wave.size();
+    h_items = static_cast<FineState*>(c.h_items.need((size_t)nw * sizeof(FineState)));
+    for (int i = 0; i < nw; ++i) {
+        const DevCand& cd = cand[(size_t)wave[i].seg * kMaxCand + wave[i].cand];
+        FineState f{};
+        f.seg = wave[i].seg; f.freq = cd.freq; f.drift = cd.drift; f.shift = cd.shift; f.sync = cd.sync;
+        f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
+        h_items[i] = f;
+    }
+    d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
+    h_lists = static_cast<int*>(c.h_lists.need((size_t)nw * 2 * 4));
+    n_shared = n_own = 0;
+    const size_t ntabs = plan_tables(h_items, nw, h_lists, &n_shared, &n_own);
+    d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
+    d_tabs = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)nw * 5) * 2048 * 4));
+    d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
+    const int nh_max = std::max(nlag0, kMaxLags);
+    d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
+    d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
+    d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
+    const float* wi = c.iqI.as<float>();
+    const float* wq = c.iqQ.as<float>();
+    h_sync = static_cast<float*>(c.h_sync.need((size_t)nw * kMaxLags * 4));
+    h_rms = static_cast<float*>(c.h_rms.need((size_t)nw * kMaxLags * 4));
+    h_sym = static_cast<unsigned char*>(c.h_sym.need((size_t)nw * kMaxLags * kNSymD));
+    {
+        Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
+        upload(d_items, h_items, (size_t)nw * sizeof(FineState), c.stream);
+        upload(d_lists, h_lists, (size_t)nw * 2 * 4, c.stream);
+        // mode 0: lag scan (tiled), mode 1: 5 frequencies, mode 2: first rung of the ladder
+        launch_phasor_tables(d_items, nw, 0, d_tabs, c.stream);
+        launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, nlag0, lagstep,
+                           0.0f, d_tabs, d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
+        launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
+        {
+            float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
+            float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
+            launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, lagstep,
+                                            minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync, d_sym,
+                                            d_rms, c.tab, c.stream);
+        }
+        HIP_OK(hipMemcpyAsync(h_items, d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)nw * kNSymD, hipMemcpyDeviceToHost, c.stream));
+        t.stop();
+    }
+
+    // ---- host: first rung of the jitter ladder ----------------------------
+    const auto t_f0 = std::chrono::steady_clock::now();
+    // a candidate that passes the gates but does not decode costs a full time-out here
+    // (milliseconds) while a decode costs microseconds: one task per grab, all threads
+    Pool& pool0 = (nw >= 256) ? *c.bigpool : *c.pool;
+    pool0.run(nw, [&](int i) {
+        WaveItem& w = wave[i];
+        w.fine = h_items[i];
+        w.worth = w.fine.sync > minsync1;
+        w.decoded = false;
+        w.jitter = 0;
+        if (!w.worth) return;
+        if (h_sync[i] > minsync2 && h_rms[i] > minrms) {
+            unsigned char sym[kNSymD];
+            memcpy(sym, h_sym + (size_t)i * kNSymD, kNSymD);
+            deinterleave162(sym);
+            unsigned metric, maxnp;
+            memset(w.decdata, 0, sizeof w.decdata);
+            const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
+            w.decoded = (nd == 0);
+            w.rung0_pending = (nd != 0) && fast;
+            if (!w.rung0_pending) { c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++; }
+        }
+    }, nw >= 256 ? 1 : 0);
+    c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
+
+    if (fast)
+        for (int i = 0; i < nw; ++i)
+            if (wave[i].rung0_pending) pend.add(wave[i].seg, h_sym + (size_t)i * kNSymD);
+}
+
+// Remaining rungs of the jitter ladder, only for candidates that still need them
+void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
+    const int nw = (int)wave.size();
+    const float* wi = c.iqI.as<float>();
+    const float* wq = c.iqQ.as<float>();
+    std::vector<int> again;
+    if (njit_rest > 0)
+        for (int i = 0; i < nw; ++i)
+            if (wave[i].worth && !wave[i].decoded) again.push_back(i);
+    if (!again.empty()) {
+        const int na = (int)again.size();
+        FineState* h2 = static_cast<FineState*>(c.h_misc.need((size_t)na * sizeof(FineState)));
+        for (int a = 0; a < na; ++a) h2[a] = wave[again[a]].fine;
+        const size_t ntabs2 = plan_tables(h2, na, h_lists, &n_shared, &n_own);
+        d_tabs = static_cast<float*>(c.tabs.need(ntabs2 * 2048 * 4));
+        {
+            // all 43 lags shift-63 .. shift+63 in steps of 3 (rung r of the ladder = lag index
+            // (jitter+63)/3; index 21 repeats rung 0 and is ignored)
+            Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
+            upload(d_items, h2, (size_t)na * sizeof(FineState), c.stream);
+            upload(d_lists, h_lists, (size_t)na * 2 * 4, c.stream);
+            launch_phasor_tables(d_items, na, 2, d_tabs, c.stream);
+            launch_demod_tiled(wi, wq, samples, d_items, na, d_lists, n_shared, d_lists + na, n_own, 2, kMaxLags, 3,
+                               minsync1, d_tabs, d_pw, d_sync, d_sym, d_rms, c.tab, c.stream);
+            HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * kMaxLags * kNSymD, hipMemcpyDeviceToHost, c.stream));
+            t.stop();
+        }
+        const auto t_f1 = std::chrono::steady_clock::now();
+        // every (candidate, rung) Fano attempt is independent; the ladder keeps the
+        // FIRST success in rung order, so run them all and pick afterwards
+        struct Attempt { int ok; int pending; unsigned cycles; unsigned char data[11]; };
+        std::vector<Attempt> att((size_t)na * njit_rest);
+        std::vector<std::atomic<int>> first(na);
+        for (auto& f : first) f.store(njit_rest);
+        Pool& fpool = (na * njit_rest >= 256) ? *c.bigpool : *c.pool;
+        // rung-major order and one task per grab: a time-out costs ~810 000 decoder cycles
+        // (milliseconds) while a success costs microseconds, so costs are heavy-tailed; low
+        // rungs finish first and cancel the higher rungs of the same candidate
+        fpool.run(na * njit_rest, [&](int task) {
+            const int r = task / na, a = task % na;
+            const int idx = a * njit_rest + r;
+            Attempt& at = att[idx];
+            at.ok = 0;
+            at.pending = 0;
+            if (r > first[a].load()) return;           // an earlier rung already decoded
+            const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
+            if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
+            unsigned char sym[kNSymD];
+            memcpy(sym, h_sym + g * kNSymD, kNSymD);
+            deinterleave162(sym);
+            unsigned metric, maxnp;
+            memset(at.data, 0, sizeof at.data);
+            const int nd = fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles);
+            at.pending = (nd != 0) && fast;
+            if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
+            if (nd == 0) {
+                at.ok = 1;
+                int cur = first[a].load();
+                while (r < cur && !first[a].compare_exchange_weak(cur, r)) {}
+            }
+        }, 1);
+        if (fast)      // unfinished attempts on rungs BEFORE the accepted one decide nothing yet
+            for (int a = 0; a < na; ++a) {
+                const int rmax = std::min(first[a].load(), njit_rest);
+                for (int r = 0; r < rmax; ++r)
+                    if (att[(size_t)a * njit_rest + r].pending) {
+                        const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
+                        pend.add(wave[again[a]].seg, h_sym + g * kNSymD);
+                    }
+            }
+        for (int a = 0; a < na; ++a) {
+            const int r = first[a].load();
+            if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
+                WaveItem& w = wave[again[a]];
+                w.decoded = true;
+                w.jitter = c.jitter_ladder[r + 1];
+                w.cycles = att[(size_t)a * njit_rest + r].cycles;
+                memcpy(w.decdata, att[(size_t)a * njit_rest + r].data, 11);
+            }
+        }
+        c.t_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f1).count();
+    }
+}
+
+// Host bookkeeping in candidate order (wsprd.c:768-822).  Items of one segment are contiguous in the
+// wave and must be handled in order; different segments are independent -> one pool task per segment.
+// Returns the subtraction jobs of the wave.
+std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) {
+    const int nw = (int)wave.size();
+    const auto t_b0 = std::chrono::steady_clock::now();
+    std::vector<int> group_start;
+    for (int i = 0; i < nw; ++i)
+        if (i == 0 || wave[i].seg != wave[i - 1].seg) group_start.push_back(i);
+    group_start.push_back(nw);
+    const int ngroups = (int)group_start.size() - 1;
+    std::vector<SubJob> job_of(nw);
+    std::vector<char> has_job(nw, 0);
+    c.pool->run(ngroups, [&](int g) {
+      const int sg = wave[group_start[g]].seg;
+      bool cut = false;
+      for (int i = group_start[g]; i < group_start[g + 1] && !cut; ++i) {
+        WaveItem& w = wave[i];
+        const int s = w.seg;
+        if (stopped[s]) break;
+        if (lockstep) next_cand[s] = w.cand + 1;
+        DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
+        cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
+        if (!(w.worth && w.decoded)) continue;
+
+        signed char message[12] = {0};
+        for (int k = 0; k < 11; ++k) message[k] = (signed char)w.decdata[k];
+        char callsign[13] = {0}, call_loc_pow[23] = {0}, call[13] = {0}, loc[7] = {0}, pwr[3] = {0};
+        SegBook& bk = book[s];
+        const int noprint = unpack_message(message, hashtab_of(s), loctab_of(s), call_loc_pow, call, loc, pwr, callsign);
+        bk.dirty.push_back((int)nhash15(callsign, strlen(callsign), 146u));
+        if (opt.subtraction && ipass == 0 && !noprint) {
+            SubJob jb{};
+            if (channel_symbols(call_loc_pow, hashtab_of(s), loctab_of(s), jb.sym)) {
+                jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
+                job_of[i] = jb;
+                has_job[i] = 1;
+                cut = true;            // the IQ changes: later candidates of this window are redone
+            } else {
+                stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
+                continue;
+            }
+        }
+        if (!strcmp(loc, "A000AA")) { stopped[s] = 1; continue; }      // wsprd.c:792-793
+        bool dupe = false;
+        for (int u = 0; u < bk.uniques; ++u)
+            if (!strcmp(callsign, bk.allcalls[u]) && fabs(w.fine.freq - bk.allfreqs[u]) < 3.0) dupe = true;
+        if (dupe || bk.uniques >= 100) continue;
+        snprintf(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], "%s", callsign);
+        bk.allfreqs[bk.uniques] = w.fine.freq;
+        bk.uniques++;
+        if (bk.uniques <= max_results) {
+            decoder_results* o = out + (size_t)s * max_results + (bk.uniques - 1);
+            const double dial = (double)opt.freq / 1e6;
+            o->sync = w.fine.sync;
+            // candidates[j].snr, wsprd.c:616, recomputed with the host libm from the
+            // peak value so that the reported figure does not depend on ocml's log10f
+            o->snr = 10.0 * log10f(cd.peak) - (float)26.3;
+            o->dt = w.fine.shift * 1.0 / 375.0 - 2.0;
+            o->freq = dial + (1500.0 + w.fine.freq) / 1e6;
+            o->drift = w.fine.drift;
+            o->cycles = (int)w.cycles;
+            o->jitter = w.jitter;
+            snprintf(o->message, sizeof o->message, "%s", call_loc_pow);
+            snprintf(o->call, sizeof o->call, "%s", call);
+            snprintf(o->loc, sizeof o->loc, "%s", loc);
+            snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
+        }
+      }
+      if (lockstep) win[sg] = cut ? 1 : std::min(64, 2 * win[sg]);
+    });
+    std::vector<SubJob> jobs;
+    for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);
+    c.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b0).count();
+    return jobs;
+}
+
+// GPU: subtract everything that decoded in this wave
+void Context::DecodeRun::subtract(const std::vector<SubJob>& jobs) {
+    if (jobs.empty()) return;
+    const int nj = (int)jobs.size();
+    SubJob* hj = static_cast<SubJob*>(c.h_jobs.need((size_t)nj * sizeof(SubJob)));
+    memcpy(hj, jobs.data(), (size_t)nj * sizeof(SubJob));
+    SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nj * sizeof(SubJob)));
+    float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nj) * 4));
+    Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[4]);
+    upload(dj, hj, (size_t)nj * sizeof(SubJob), c.stream);
+    launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nj, scratch, c.tab, c.stream);
+    t.stop();
+}
+
+// results strongest first (wsprd.c:827; stable like glibc's merge sort); hash slots written by the
+// batch are cleared again
+void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results) {
     for (int s : active0) {
         SegBook& bk = book[s];
         const int n = std::min(bk.uniques, max_results);
@@ -901,15 +950,35 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
             memset(loctab_of(s) + (size_t)slot * kLocWidth, 0, kLocWidth);
         }
     }
-    if (persist) {                                            // wsprd.c:842-852
-        if (FILE* fh = fopen("hashtable.txt", "w")) {
-            for (int i = 0; i < kHashSlots; ++i)
-                if (hashtab_of(0)[i * kHashWidth] != '\0')
-                    fprintf(fh, "%5d %s %s\n", i, hashtab_of(0) + i * kHashWidth, loctab_of(0) + i * kLocWidth);
-            fclose(fh);
+    save_hash_file();
+}
+
+// One full decode (all passes) of the segments in `active0`.  fast = 0: the host Fano pool runs the
+// reference's full cycle budget (exact on its own).  fast > 0: it runs `fast` cycles per bit and
+// records every attempt it could not finish in `pend` (see decode_resident).
+int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
+                         int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend) {
+    for (int s : active0) n_results[s] = 0;
+    DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
+    run.load_hash_file();
+    std::vector<int> active = active0;
+    for (int ipass = 0; ipass < opt.npasses; ++ipass) {
+        if (ipass == 1) {                                      // wsprd.c:522-523
+            std::vector<int> keep;
+            for (int s : active) if (run.book[s].uniques > 0) keep.push_back(s);
+            active.swap(keep);
         }
-        memset(hashtab_of(0), 0, per_seg);                   // the arena is reused by later batches
+        if (active.empty()) break;
+        run.start_pass(ipass, active);
+        for (;;) {
+            std::vector<WaveItem> wave = run.build_wave(active);
+            if (wave.empty()) break;
+            run.refine_and_first_rung(wave);
+            run.remaining_rungs(wave);
+            run.subtract(run.keep_books(wave));
+        }
     }
+    run.finish(active0, n_results);
     return 0;
 }
 
