@@ -184,6 +184,9 @@ def main():
                          "u8 IQ through the on-GPU decimator; --segments raw segments resident per step, default 64)")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches in flight (default 2 when the rank has >= 6 CPUs, else 1): step k+1 starts "
+                         "under the tail of step k, each on its own lane of the library")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,34 +228,68 @@ def main():
     opt = w.default_options()
     if use_dist:
         opt = wd.broadcast_options(opt, src=0)          # fan-out of the (tiny) job description
-    dec = w.BatchDecoder(nseg, max_results=16 if args.config == 2 else 32, options=opt)
+    # Steps are pipelined the way a service would run them: `inflight` batches at a time, each decoded by
+    # its own host thread on its own lane of the library (own streams, buffers, host pools), so that the
+    # serial tail of step k (last slot, result sorting, copies) is covered by the start of step k+1.
+    # Every step is still one complete pass over one batch, and all K timed steps finish inside the fences.
+    cpus_here = int(os.environ["WSPR_HOST_THREADS"])
+    inflight = args.inflight if args.inflight else (2 if cpus_here >= 6 else 1)
+    inflight = max(1, min(inflight, 4))
+    from concurrent.futures import ThreadPoolExecutor
+    lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
+
+    def bind(lane):
+        torch.cuda.set_device(local)
+        return w.lib().wspr_bind_thread_lane(lane)
+    for k, ex in enumerate(lanes):
+        assert ex.submit(bind, k).result() == k
     rec = C.sizeof(w.decoder_results)
+    decs = [w.BatchDecoder(nseg, max_results=16 if args.config == 2 else 32, options=opt) for _ in range(inflight)]
+    dec = decs[0]
+    gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
+    if args.config == 5:                                  # the decimator's output rows, one set per lane
+        IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
 
-    gatherer = wd.SpotGatherer(dec.out, dec.nres, nseg, dec.max_results, rec, dst=0) if use_dist else None
-
-    def step():
+    def decode_on(k):
         if args.config == 5:
-            rc = w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 1)
+            Ik, Qk = IQs[k]
+            rc = w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, Ik.data_ptr(), Qk.data_ptr(), 1)
             assert rc == 0
-            dec.decode_ptr(I.data_ptr(), Q.data_ptr(), NS, I.stride(0))
+            decs[k].decode_ptr(Ik.data_ptr(), Qk.data_ptr(), NS, Ik.stride(0))
         else:
-            dec.decode(I, Q)
-        if use_dist:
-            return gatherer.gather()            # spot records of every rank land on rank 0 (RCCL)
-        return None
+            decs[k].decode(I, Q)
+        return k
+
+    def run_steps(n):
+        """n steps, at most `inflight` of them running; spot records are gathered in step order."""
+        pending, last = [], None
+        for s in range(n):
+            done = None
+            if len(pending) >= inflight:
+                done = pending.pop(0).result()
+                if use_dist:
+                    gatherers[done].stage()                   # results copied out: the lane is free again
+            pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
+            if done is not None and use_dist:
+                last = gatherers[done].exchange()             # every rank's records land on rank 0 (RCCL)
+        for fut in pending:
+            k = fut.result()
+            if use_dist:
+                last = gatherers[k].gather()
+        return last
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
+    # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
+    untimed = max(args.warmup, 4 * inflight)
+    run_steps(untimed)
     fence()
     t0 = time.perf_counter()
-    gathered = None
-    for _ in range(args.steps):
-        gathered = step()
+    gathered = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -261,6 +298,7 @@ def main():
         elapsed = float(tmax.item())
 
     # correctness of what was timed: every segment's message must be the transmitted one
+    dec = decs[(args.steps - 1) % inflight] if args.steps > 0 else decs[0]      # the last step's results
     got = [[s.message.decode() for s in dec.spots(i)] for i in range(nseg)]
     n_sent = sum(len(e) for e in expected)
     n_ok = sum(len(set(expected[i]) & set(got[i])) for i in range(nseg))
@@ -318,7 +356,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", 45000 complex f32 samples @ 375 sps, resident in HBM; reference "
                                    "defaults (npasses 2, subtraction on, quickmode off)",
-                       "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0"},
+                       "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0",
+                       "batches_in_flight": inflight, "untimed_steps": untimed},
             "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
             "stage_ms_last_step": timings, "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},

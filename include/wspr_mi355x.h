@@ -177,6 +177,11 @@ int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int sa
  * Outputs per vector: ret (0 / -1), cycles, metric, maxnp, data[10]. */
 int wspr_fano_batch_device(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
                            unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data);
+/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to four
+ * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
+ * this (returns the lane actually bound, 0..3); calls made from threads bound to different lanes may
+ * overlap, e.g. to start the next batch under the tail of the current one. */
+int wspr_bind_thread_lane(int lane);
 /* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
  * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with
  * the reference's 10000, and a segment in which one of those decodes after all is decoded again with

@@ -45,7 +45,7 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
         if (writeback) c0.store_host(idat, qdat, nseg, samples, seg_stride);
         return rc;
     }
-    const int dev = c0.device();
+    const int dev = c0.device(), lane = Context::lane();
     std::vector<std::thread> th;
     std::vector<int> rcs(nslots, 0);
     std::vector<std::string> errs(nslots);
@@ -54,6 +54,7 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
         th.emplace_back([&, g, lo, hi] {
             try {
                 if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+                Context::bind_lane(lane);
                 Context& c = Context::slot(g);
                 load(c, lo, hi - lo);
                 rcs[g] = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results,
@@ -244,6 +245,11 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
         c.sync();
         return 0;
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
+}
+
+int wspr_bind_thread_lane(int lane) {
+    Context::bind_lane(lane);
+    return Context::lane();
 }
 
 unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {

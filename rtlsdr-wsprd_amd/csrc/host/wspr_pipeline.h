@@ -27,6 +27,9 @@ public:
     static Context& get();          // slot 0; throws std::runtime_error when no HIP device is usable
     static Context& slot(int i);    // i in [0, slots())
     static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
+    static constexpr int kMaxLanes = 4;
+    static int lane();              // lane of the calling thread
+    static void bind_lane(int lane);
     int device();
     ~Context();
 

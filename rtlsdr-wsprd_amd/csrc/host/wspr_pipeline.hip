@@ -282,12 +282,20 @@ int Context::slots() {
     return n;
 }
 
+// Lanes: independent sets of slot contexts.  A host thread is bound to one lane (default 0); calls
+// made from threads bound to different lanes share nothing but the device and may overlap, which
+// lets a service pipeline batch k+1 under the tail of batch k.
+static thread_local int t_lane = 0;
+int Context::lane() { return t_lane; }
+void Context::bind_lane(int lane) { t_lane = std::max(0, std::min(lane, kMaxLanes - 1)); }
+
 Context& Context::slot(int i) {
     static std::mutex m;
-    static std::unique_ptr<Context> ctx[8];
+    static std::unique_ptr<Context> ctx[kMaxLanes][8];
     std::lock_guard<std::mutex> g(m);
-    if (!ctx[i]) ctx[i].reset(new Context(slots()));
-    return *ctx[i];
+    std::unique_ptr<Context>& p = ctx[t_lane][i];
+    if (!p) p.reset(new Context(slots()));
+    return *p;
 }
 
 Context& Context::get() { return slot(0); }

@@ -73,6 +73,11 @@ class SpotGatherer:
         self.cnt_src = torch.from_numpy(np.frombuffer(counts, dtype=np.int32).reshape(nseg))
         self.rec_dev = torch.empty_like(self.rec_src, device=dev)
         self.cnt_dev = torch.empty_like(self.cnt_src, device=dev)
+        pin_src = self.nccl
+        self.rec_stage = torch.empty(self.rec_src.shape, dtype=torch.uint8, pin_memory=pin_src)
+        self.cnt_stage = torch.empty(self.cnt_src.shape, dtype=torch.int32, pin_memory=pin_src)
+        self._rec_src_np, self._cnt_src_np = self.rec_src.numpy(), self.cnt_src.numpy()
+        self._rec_stage_np, self._cnt_stage_np = self.rec_stage.numpy(), self.cnt_stage.numpy()
         if self.rank == dst:
             self.rec_all = [torch.empty_like(self.rec_dev) for _ in range(self.world)]
             self.cnt_all = [torch.empty_like(self.cnt_dev) for _ in range(self.world)]
@@ -82,10 +87,22 @@ class SpotGatherer:
         else:
             self.rec_all = self.cnt_all = None
 
+    def stage(self):
+        """Host copy of the decoder's result arrays into the gatherer's own (pinned) staging buffers;
+        afterwards the decoder may be reused while exchange() runs."""
+        # plain memcpy through numpy views (a torch CPU copy would wake its intra-op thread pool)
+        np.copyto(self._rec_stage_np, self._rec_src_np)
+        np.copyto(self._cnt_stage_np, self._cnt_src_np)
+
     def gather(self):
+        """stage() + exchange()."""
+        self.stage()
+        return self.exchange()
+
+    def exchange(self):
         """Returns (counts [world, nseg] int32, records [world, nseg, K*record] uint8) on dst, else None."""
-        self.rec_dev.copy_(self.rec_src, non_blocking=True)
-        self.cnt_dev.copy_(self.cnt_src, non_blocking=True)
+        self.rec_dev.copy_(self.rec_stage, non_blocking=True)
+        self.cnt_dev.copy_(self.cnt_stage, non_blocking=True)
         dist.gather(self.rec_dev, self.rec_all, dst=self.dst)
         dist.gather(self.cnt_dev, self.cnt_all, dst=self.dst)
         if self.rank != self.dst:
