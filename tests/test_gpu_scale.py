@@ -181,3 +181,33 @@ def test_many_receivers_streaming_decimator_equals_oracle(env):
     assert states.cpu().numpy()[:, 0].tolist() == [(chunk_samples * nchunks) % 6401] * nrx
     for st in ost:
         L.orc_decim_free(C.c_void_p(st))
+
+
+def test_two_lanes_decode_concurrently_and_identically(env):
+    """Host threads bound to different lanes (wspr_bind_thread_lane) decode different batches at the same
+    time; each gets exactly what a lone, sequential decode of its batch gives."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch, bench, w, dev = env
+    nseg = 384
+    batches = [bench.synth_batch_gpu(nseg, 900 + k, dev, 2 if k else 1, -14.0, -22.0, 0.5)[:2] for k in range(2)]
+    solo = []
+    for I, Q in batches:
+        d = w.BatchDecoder(nseg, 16)
+        d.decode(I, Q)
+        solo.append([[_tup(x) for x in d.spots(s)] for s in range(nseg)])
+    assert solo[0] != solo[1] and sum(len(x) for x in solo[1]) > nseg
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        assert w.lib().wspr_bind_thread_lane(k) == k
+        d = w.BatchDecoder(nseg, 16)
+        res = []
+        for _ in range(6):
+            d.decode(*batches[k])
+            res.append([[_tup(x) for x in d.spots(s)] for s in range(nseg)])
+        return res
+    with ThreadPoolExecutor(2) as ex:
+        futs = [ex.submit(worker, k) for k in range(2)]
+        out = [f.result() for f in futs]
+    for k in range(2):
+        assert all(r == solo[k] for r in out[k]), k
