@@ -4,6 +4,8 @@
 #include <chrono>
 #include <atomic>
 #include <functional>
+#include <string>
+#include <unordered_map>
 #include <memory>
 #include <vector>
 
@@ -20,6 +22,23 @@ struct PendingFano {
     std::vector<int> seg;                 // owning segment of each attempt
     std::vector<unsigned char> sym;       // 162 soft symbols each, transmission order
     void add(int s, const unsigned char* v) { seg.push_back(s); sym.insert(sym.end(), v, v + 162); }
+};
+
+// Exact full-budget results of Fano attempts that were already run, keyed by the soft-symbol vector
+// (the search is a pure function of it): the re-decode of a segment replays the same vectors up to
+// the point where the late success changes the IQ, and takes their results from here.
+struct FanoMemo {
+    struct Entry { int ret; unsigned cycles; unsigned char data[11]; };
+    std::unordered_map<std::string, Entry> map;
+    void add(const unsigned char* sym, int ret, unsigned cycles, const unsigned char* data10) {
+        Entry e{ret, cycles, {0}};
+        for (int k = 0; k < 10; ++k) e.data[k] = data10[k];
+        map.emplace(std::string(reinterpret_cast<const char*>(sym), 162), e);
+    }
+    const Entry* find(const unsigned char* sym) const {
+        const auto it = map.find(std::string(reinterpret_cast<const char*>(sym), 162));
+        return it == map.end() ? nullptr : &it->second;
+    }
 };
 
 class Context {
@@ -59,7 +78,8 @@ public:
                         int max_results, int* n_results,
                         const std::function<void(const std::vector<int>&)>& reload = nullptr);
     int decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
-                    int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend);
+                    int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend,
+                    const FanoMemo* memo = nullptr);
     int last_timings(double* ms, int cap);
     int bench_fft_sync(int nseg, int samples, int iters, double* ms);
 

@@ -498,8 +498,11 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
         if (!redo.empty()) {
             // ---- exact re-decode of the few segments where a late success changes the story ----
             reload(redo);
+            FanoMemo memo;
+            for (int i = 0; i < np; ++i)
+                if (dirty[pend.seg[i]]) memo.add(pend.sym.data() + (size_t)i * kNSymD, ret[i], cyc[i], dat.data() + (size_t)i * 10);
             PendingFano none;
-            decode_core(nseg, samples, opt, out, max_results, n_results, redo, 0u, none);
+            decode_core(nseg, samples, opt, out, max_results, n_results, redo, 0u, none, &memo);
         }
     }
     c.t_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all0).count();
@@ -519,6 +522,23 @@ struct Context::DecodeRun {
     const int max_results;
     const unsigned fast;                      // host Fano budget (cycles per bit) or 0 = the reference's
     PendingFano& pend;
+    const FanoMemo* memo = nullptr;           // results already known (re-decode after a late success)
+
+    // one Fano attempt on a soft-symbol vector in transmission order (wsprd.c:759-761)
+    int fano_attempt(const unsigned char* tx_sym, unsigned* cycles, unsigned char* data11) const {
+        memset(data11, 0, 11);
+        if (memo)
+            if (const FanoMemo::Entry* e = memo->find(tx_sym)) {
+                *cycles = e->cycles;
+                memcpy(data11, e->data, 11);
+                return e->ret;
+            }
+        unsigned char sym[kNSymD];
+        memcpy(sym, tx_sym, kNSymD);
+        deinterleave162(sym);
+        unsigned metric, maxnp;
+        return fano_decode(&metric, cycles, &maxnp, data11, sym, kNBits, met.tab, delta, maxcycles);
+    }
 
     // tuning constants of wsprd.c:423-433
     const float minsync1 = 0.10f;
@@ -748,12 +768,7 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
         w.jitter = 0;
         if (!w.worth) return;
         if (h_sync[i] > minsync2 && h_rms[i] > minrms) {
-            unsigned char sym[kNSymD];
-            memcpy(sym, h_sym + (size_t)i * kNSymD, kNSymD);
-            deinterleave162(sym);
-            unsigned metric, maxnp;
-            memset(w.decdata, 0, sizeof w.decdata);
-            const int nd = fano_decode(&metric, &w.cycles, &maxnp, w.decdata, sym, kNBits, met.tab, delta, maxcycles);
+            const int nd = fano_attempt(h_sym + (size_t)i * kNSymD, &w.cycles, w.decdata);
             w.decoded = (nd == 0);
             w.rung0_pending = (nd != 0) && fast;
             if (!w.rung0_pending) { c.n_fano++; c.n_cycles += w.cycles; if (nd) c.n_timeout++; }
@@ -815,12 +830,7 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             if (r > first[a].load()) return;           // an earlier rung already decoded
             const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
             if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
-            unsigned char sym[kNSymD];
-            memcpy(sym, h_sym + g * kNSymD, kNSymD);
-            deinterleave162(sym);
-            unsigned metric, maxnp;
-            memset(at.data, 0, sizeof at.data);
-            const int nd = fano_decode(&metric, &at.cycles, &maxnp, at.data, sym, kNBits, met.tab, delta, maxcycles);
+            const int nd = fano_attempt(h_sym + g * kNSymD, &at.cycles, at.data);
             at.pending = (nd != 0) && fast;
             if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
             if (nd == 0) {
@@ -965,9 +975,11 @@ void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results)
 // reference's full cycle budget (exact on its own).  fast > 0: it runs `fast` cycles per bit and
 // records every attempt it could not finish in `pend` (see decode_resident).
 int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
-                         int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend) {
+                         int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend,
+                         const FanoMemo* memo) {
     for (int s : active0) n_results[s] = 0;
     DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
+    run.memo = memo;
     run.load_hash_file();
     std::vector<int> active = active0;
     for (int ipass = 0; ipass < opt.npasses; ++ipass) {
