@@ -213,8 +213,8 @@ def main():
         if nseg >= 6144 and "WSPR_FANO_FAST" not in os.environ:
             # crowded band, thousands of Fano time-outs per step: short host budget + device tail (K6);
             # results are those of the full budget by construction
-            w.lib().wspr_set_fano_fast_budget(C.c_uint(600))
-            workload += "; Fano budget split 600 cycles/bit on the host pool + device tail"
+            w.lib().wspr_set_fano_fast_budget(C.c_uint(300))
+            workload += "; Fano budget split 300 cycles/bit on the host pool + device tail"
     else:
         raw, expected = synth_raw_gpu(nseg, 777 + rank, dev, args.snr)
         stride = int(w.lib().wspr_iq_stride())
