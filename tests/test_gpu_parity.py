@@ -235,6 +235,22 @@ def test_randomised_scenes_equal_oracle(w):
     assert total > 40 and len(got[0]) == 0
 
 
+def test_committed_scene_spots_without_the_oracle(w):
+    """The product against tests/golden/scene_spots.json alone (no oracle call in the loop): every field
+    of every spot, SNR to the stated 0.1 dB."""
+    import json
+    import scenes
+    gold = json.load(open(os.path.join(ol.GOLDEN, "scene_spots.json")))["scenes"]
+    I = np.stack([scenes.make_scene(g["seed"])[0] for g in gold])
+    Q = np.stack([scenes.make_scene(g["seed"])[1] for g in gold])
+    got = w.wspr_decode_batch(I, Q, w.default_options())
+    for g, spots in zip(gold, got):
+        rec = [scenes.spot_record(s) for s in spots]
+        assert [{k: v for k, v in r.items() if k != "snr"} for r in rec] == \
+               [{k: v for k, v in r.items() if k != "snr"} for r in g["spots"]], g["seed"]
+        assert all(abs(a["snr"] - b["snr"]) <= 0.1 for a, b in zip(rec, g["spots"]))
+
+
 def test_empty_and_degenerate_inputs(w):
     z = np.zeros((2, NS), np.float32)
     assert w.wspr_decode_batch(z, z) == [[], []]

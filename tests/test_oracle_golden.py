@@ -238,3 +238,17 @@ def test_oracle_equals_real_reference_objects_on_random_inputs():
              (m >> 10) & 255, (m >> 2) & 255, (m & 3) << 6]
         v = {"data": d, "pre_hash": []}
         assert _unpk(L, "orc_unpk", v) == _unpk(R, "unpk_", v)
+
+
+def test_oracle_reproduces_committed_scene_spots():
+    """tests/golden/scene_spots.json (made by make_scene_vectors.py from this oracle): a regression pin --
+    any edit of oracle/ that changes a decision or a reported float shows up here."""
+    import json
+    import scenes
+    gold = json.load(open(os.path.join(ol.GOLDEN, "scene_spots.json")))["scenes"]
+    assert [g["seed"] for g in gold] == scenes.GOLDEN_SEEDS
+    for g in gold:
+        I, Q = scenes.make_scene(g["seed"])
+        spots, _, _ = ol.decode(I, Q, scenes.NS)
+        assert [scenes.spot_record(s) for s in spots] == g["spots"], g["seed"]
+    assert sum(len(g["spots"]) for g in gold) >= 25
