@@ -429,15 +429,16 @@ struct Timer {
 
 }  // namespace
 
-// Assigns each item its slot in the phasor-table buffer (1 table without drift, 162 with) and
-// splits the items into the two launch lists of the tiled demodulator.  Returns the table count.
+// Assigns each drift-free item its slot in the phasor-table buffer (drifting ones build their 162
+// per-symbol tables inside the kernel) and splits the items into the two launch lists of the tiled
+// demodulator.  Returns the table count.
 static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, int* n_own) {
     size_t next = 0;
     int ns = 0, no = 0;
     for (int i = 0; i < n; ++i) {
         items[i].pad = (int)next;
-        if (items[i].drift != 0.0f) { next += kNSymD; lists[n + no++] = i; }
-        else                        { next += 1;      lists[ns++] = i; }
+        if (items[i].drift != 0.0f) { lists[n + no++] = i; }
+        else                        { next += 1; lists[ns++] = i; }
     }
     *n_shared = ns;
     *n_own = no;

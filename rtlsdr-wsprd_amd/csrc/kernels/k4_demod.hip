@@ -198,14 +198,14 @@ void phasor_table_kernel(const FineState* __restrict__ items, int mode, float* _
     const FineState st = items[item];
     const int lane = threadIdx.x;
     const int sym = blockIdx.x * 16 + (lane >> 2), tone = lane & 3;
-    const bool drifting = st.drift != 0.0f;
-    if (sym >= kNSymD || (!drifting && sym != 0)) return;
+    // drifting candidates build their per-symbol tables inside demod_tile_kernel<., false>
+    if (st.drift != 0.0f || sym != 0) return;
     const float f0 = (mode == 0) ? st.freq_coarse : st.freq;
     const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)((float)sym - 81.0f) / (double)81.0f);
     const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
     const float dphi = (float)(kTwoPiDt * ((double)fp + off));
     const float cd = glibc_cosf(dphi), sd = glibc_sinf(dphi);
-    float* __restrict__ t = tabs + ((size_t)st.pad + (drifting ? sym : 0)) * 2048;   // [256][8]
+    float* __restrict__ t = tabs + (size_t)st.pad * 2048;   // [256][8]
     float c = 1.0f, s = 0.0f;
     for (int j = 0; j < kSps; ++j) {
         if (j > 0) {
@@ -236,18 +236,44 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const int span = kSps * kTileSyms + STEP * (nlag - 1);
     const int pitch = (span + STEP - 1) / STEP + 1;
 
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)st.pad + (SHARED ? 0 : i0)) * 512;
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int kbase = lag0 + kSps * i0;
     const int nthr = blockDim.x;
-    // prologue: issue loads in batches of 4 so that their latencies overlap
-    for (int e0 = tid; e0 < ntab * 512; e0 += 4 * nthr) {
-        float4 v[4];
+    if constexpr (SHARED) {
+        // the candidate's one table (built by phasor_table_kernel); loads in batches of 4 so that their
+        // latencies overlap
+        const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)st.pad * 512;
+        for (int e0 = tid; e0 < 512; e0 += 4 * nthr) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < ntab * 512) v[u] = gt[e]; }
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) v[u] = gt[e]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < ntab * 512) tab[e] = v[u]; }
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) tab[e] = v[u]; }
+        }
+    } else {
+        // a drifting candidate has one table per symbol (162 x 8 KB): its 6 x 4 phasor recurrences are run
+        // here by the first 24 lanes, straight into LDS, instead of travelling through HBM (2.6 MB per
+        // candidate written and read back); same operations as phasor_table_kernel (wsprd.c:158-188)
+        if (tid < kTileSyms * 4) {
+            const int il = tid >> 2, tone = tid & 3, sym = i0 + il;
+            const float f0 = (mode == 0) ? st.freq_coarse : st.freq;
+            const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)((float)sym - 81.0f) / (double)81.0f);
+            const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
+            const float dphi = (float)(kTwoPiDt * ((double)fp + off));
+            const float cd = glibc_cosf(dphi), sd = glibc_sinf(dphi);
+            float* __restrict__ t = reinterpret_cast<float*>(tab + il * 512);     // [256][8]
+            float c = 1.0f, s = 0.0f;
+            for (int j = 0; j < kSps; ++j) {
+                if (j > 0) {
+                    const float a = c * cd, b = s * sd, e = c * sd, d = s * cd;
+                    c = a - b;
+                    s = e + d;
+                }
+                t[8 * j + tone] = c;
+                t[8 * j + 4 + tone] = s;
+            }
+        }
     }
     for (int e0 = tid; e0 < span; e0 += 4 * nthr) {
         float2 v[4];
@@ -584,7 +610,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
 
 void launch_phasor_tables(const FineState* items, int nitems, int mode, float* tabs, hipStream_t st) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(phasor_table_kernel, dim3((kNSymD + 15) / 16, nitems), dim3(64), 0, st, items, mode, tabs);
+    hipLaunchKernelGGL(phasor_table_kernel, dim3(1, nitems), dim3(64), 0, st, items, mode, tabs);
 }
 
 // item_list_shared / item_list_own: indices into items[] of the candidates without / with drift
