@@ -23,13 +23,19 @@ constexpr double kTwoPiDt = 2.0 * 3.14159265358979323846 * 1.0 / 375.0;   // TWO
 constexpr double kDf05 = 375.0 / 256.0 * 0.5;
 constexpr double kDf15 = 375.0 / 256.0 * 1.5;
 
-__global__ __launch_bounds__(192)
+constexpr int kGenThreads = 192;
+constexpr int kGenChunk = 32;
+constexpr int kGenPerThread = kNSymD * kGenChunk / kGenThreads;     // 27 samples staged per thread and chunk
+static_assert(kNSymD * kGenChunk % kGenThreads == 0, "chunk must split evenly over the workgroup");
+
+__global__ __launch_bounds__(kGenThreads)
 void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                   const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
                   int nlag, int lagstep, int ifmin, float fstep, const int* __restrict__ jitter,
                   float minsync1, float* __restrict__ sync_out, unsigned char* __restrict__ sym_out,
                   float* __restrict__ rms_out, const unsigned char* __restrict__ pr3) {
     __shared__ float pw[kNSymD][4];
+    __shared__ float2 tile[kNSymD][kGenChunk + 1];
     const int item = item_list ? item_list[blockIdx.y] : (int)blockIdx.y, hyp = blockIdx.x;
     const FineState st = items[item];
 
@@ -47,41 +53,52 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
         lag = st.shift + jitter[hyp];
     }
 
-    const int i = threadIdx.x;
+    // lane = symbol.  The samples stream through LDS in chunks of 32 per symbol (coalesced 128-byte row
+    // segments from HBM/L2, transposed so that lane = symbol reads conflict-free), the next chunk in flight
+    // in registers while the current one is consumed; the four tone phasors are the reference's float
+    // recurrences, run inline.
+    const int i = threadIdx.x, tid = threadIdx.x;
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    float cd[4], sd[4], c[4], s[4], ai[4], aq[4];
     if (i < kNSymD) {
-        const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
-        const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
         const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)((float)i - 81.0f) / (double)81.0f);
         const double fpd = (double)fp;
         const float dphi[4] = {(float)(kTwoPiDt * (fpd - kDf15)), (float)(kTwoPiDt * (fpd - kDf05)),
                                (float)(kTwoPiDt * (fpd + kDf05)), (float)(kTwoPiDt * (fpd + kDf15))};
-        float cd[4], sd[4], c[4], s[4], ai[4], aq[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             cd[t] = glibc_cosf(dphi[t]);
             sd[t] = glibc_sinf(dphi[t]);
             c[t] = 1.0f; s[t] = 0.0f; ai[t] = 0.0f; aq[t] = 0.0f;
         }
-        const int base = lag + kSps * i;
-        for (int j0 = 0; j0 < kSps; j0 += 4) {
-            float x[4], y[4];
-            const int k0 = base + j0;
-            if (k0 > 0 && k0 + 3 < np) {
+    }
+    float2 nxt[kGenPerThread];
+    auto fetch = [&](int ch) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { x[u] = xi[k0 + u]; y[u] = xq[k0 + u]; }
-            } else {
+        for (int u = 0; u < kGenPerThread; ++u) {
+            const int e = u * kGenThreads + tid, row = e >> 5, col = e & (kGenChunk - 1);
+            const int k = lag + kSps * row + kGenChunk * ch + col;
+            const bool ok = (k > 0) && (k < np);
+            nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < kSps / kGenChunk; ++ch) {
+        __syncthreads();                                             // the previous chunk has been consumed
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + u;
-                    const bool ok = (k > 0) && (k < np);
-                    x[u] = ok ? xi[k] : 0.0f;
-                    y[u] = ok ? xq[k] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u;
-                if (j0 + u > 0) {
+        for (int u = 0; u < kGenPerThread; ++u) {
+            const int e = u * kGenThreads + tid;
+            tile[e >> 5][e & (kGenChunk - 1)] = nxt[u];
+        }
+        __syncthreads();
+        if (ch + 1 < kSps / kGenChunk) fetch(ch + 1);
+        if (i < kNSymD) {
+            const int base = lag + kSps * i + kGenChunk * ch;
+#pragma unroll 4
+            for (int jj = 0; jj < kGenChunk; ++jj) {
+                const int k = base + jj;
+                if (kGenChunk * ch + jj > 0) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float a = c[t] * cd[t], b = s[t] * sd[t];
@@ -91,16 +108,19 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
                     }
                 }
                 if (k > 0 && k < np) {
+                    const float2 xy = tile[i][jj];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float m1 = x[u] * c[t], m2 = y[u] * s[t];
-                        const float m3 = x[u] * s[t], m4 = y[u] * c[t];
+                        const float m1 = xy.x * c[t], m2 = xy.y * s[t];
+                        const float m3 = xy.x * s[t], m4 = xy.y * c[t];
                         ai[t] = (ai[t] + m1) + m2;
                         aq[t] = (aq[t] - m3) + m4;
                     }
                 }
             }
         }
+    }
+    if (i < kNSymD) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float e1 = ai[t] * ai[t], e2 = aq[t] * aq[t];
