@@ -175,8 +175,8 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--segments", type=int, default=None, help="segments per GPU (default: the config's)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE.json configs index: 2 = configs[1] (1024 seg x 1 signal, -20 dB; the metric's "
