@@ -211,3 +211,40 @@ def test_two_lanes_decode_concurrently_and_identically(env):
         out = [f.result() for f in futs]
     for k in range(2):
         assert all(r == solo[k] for r in out[k]), k
+
+
+def test_two_lanes_with_fano_split_and_memo(env):
+    """Both lanes at once, each on a crowded batch with a 40 cycles/bit host Fano budget: device tails,
+    re-decodes and their memos run concurrently and every lane still reports the exact schedule's spots."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch, bench, w, dev = env
+    nseg = 900
+    L = w.lib()
+    L.wspr_set_fano_fast_budget.restype = C.c_uint
+    batches = [bench.synth_batch_gpu(nseg, 300 + k, dev, 4, -22.0, -30.0, 0.3)[:2] for k in range(2)]
+    old = L.wspr_set_fano_fast_budget(C.c_uint(10000))
+    try:
+        exact = []
+        for I, Q in batches:
+            d = w.BatchDecoder(nseg, 16)
+            d.decode(I, Q)
+            exact.append([[_tup(x) for x in d.spots(s)] for s in range(nseg)])
+        L.wspr_set_fano_fast_budget(C.c_uint(40))
+
+        def worker(k):
+            torch.cuda.set_device(0)
+            assert L.wspr_bind_thread_lane(k) == k
+            d = w.BatchDecoder(nseg, 16)
+            res = []
+            for _ in range(2):
+                d.decode(*batches[k])
+                res.append(([[_tup(x) for x in d.spots(s)] for s in range(nseg)], w.last_timings()))
+            return res
+        with ThreadPoolExecutor(2) as ex:
+            out = [f.result() for f in [ex.submit(worker, k) for k in range(2)]]
+    finally:
+        L.wspr_set_fano_fast_budget(C.c_uint(old))
+    for k in range(2):
+        for spots, tm in out[k]:
+            assert spots == exact[k], k
+            assert tm["fano_left_to_device"] > 100 and tm["segments_redecoded"] > 10
