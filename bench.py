@@ -30,7 +30,7 @@ from rtlsdr_wsprd_amd import dist as wd  # noqa: E402  (package submodule via th
 
 NS = 45000
 K1_BYTES = 360000 + 4 * 417 * 347            # IQ read once + ps rows 48..464 written
-K23_BYTES = 4 * 417 * 347 + 4000             # ps read once + candidates
+K23_BYTES = 4 * 417 * 347                    # ps read once (the <= 4 000 B of candidates are not counted)
 STAGE_BYTES = K1_BYTES + K23_BYTES           # 1 517 592 B per segment per pass
 HBM_PEAK_GBS = 8000.0
 
