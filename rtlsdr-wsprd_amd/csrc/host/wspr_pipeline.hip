@@ -76,7 +76,8 @@ struct PinBuf {
 // per-segment bookkeeping).  A job is an immutable heap object with two counters;
 // completion is "all tasks done", never "all workers checked in", so threads that
 // wake up late cost nothing, and a late thread holding an exhausted old job can never
-// touch a newer one.  Workers spin for a few tens of microseconds and then sleep.
+// touch a newer one.  Idle workers sleep on a condition variable; only the caller spins,
+// briefly, for the last tasks to finish.
 class Pool {
     struct Job {
         const std::function<void(int)>* fn;
@@ -453,8 +454,9 @@ static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, in
 // the reference's full budget, by the device Fano kernel (K6) at the end.  If any of them turns
 // out to decode after all -- which would have changed what the reference did next -- the segment
 // is decoded again from its original IQ with the host running the full budget, so the final
-// spots are exactly the reference's.  WSPR_FANO_FAST = cycles-per-bit of the fast budget
-// (default 600 = 48 600 cycles; 0 disables the split).
+// spots are exactly the reference's; the re-decode takes the results of the attempts it repeats from
+// a memo (FanoMemo).  WSPR_FANO_FAST / wspr_set_fano_fast_budget() = cycles-per-bit of the fast budget;
+// the default 10000 (the reference's own budget) means no split.
 std::atomic<unsigned>& fano_fast_budget() {
     static std::atomic<unsigned> v{[] { const char* e = getenv("WSPR_FANO_FAST"); return e ? (unsigned)atoi(e) : 10000u; }()};
     return v;
