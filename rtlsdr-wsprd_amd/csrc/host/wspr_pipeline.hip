@@ -328,6 +328,8 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
 void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {
     float* wi = work_i(nseg);
     float* wq = work_q(nseg);
+    if (launch_load_rows(static_cast<const float*>(dI), static_cast<const float*>(dQ), stride, samples, nseg, wi, wq, d->stream))
+        return;
     zero_tail(wi, wq, nseg, samples, d->stream);
     HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, dI, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));
     HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, dQ, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));

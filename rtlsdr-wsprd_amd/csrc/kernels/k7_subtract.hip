@@ -238,6 +238,32 @@ void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int 
                        dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
 }
 
+// Working copy of resident input: rows of `samples` floats (16-byte aligned, stride a multiple of 4) into
+// rows of kIqStride floats with a zero tail, I and Q in one launch of 16-byte accesses.
+namespace {
+__global__ __launch_bounds__(256)
+void load_rows_kernel(const float4* __restrict__ sI, const float4* __restrict__ sQ, size_t src_row4, int n4,
+                      float4* __restrict__ dI, float4* __restrict__ dQ) {
+    const int seg = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    constexpr int kRow4 = kIqStride / 4;
+    if (e >= kRow4) return;
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    dI[(size_t)seg * kRow4 + e] = e < n4 ? sI[(size_t)seg * src_row4 + e] : z;
+    dQ[(size_t)seg * kRow4 + e] = e < n4 ? sQ[(size_t)seg * src_row4 + e] : z;
+}
+}  // namespace
+
+bool launch_load_rows(const float* sI, const float* sQ, size_t stride, int samples, int nseg, float* dI, float* dQ,
+                      hipStream_t st) {
+    if ((samples & 3) || (stride & 3) || (reinterpret_cast<uintptr_t>(sI) & 15) || (reinterpret_cast<uintptr_t>(sQ) & 15))
+        return false;                                        // the caller falls back to strided copies
+    if (nseg <= 0) return true;
+    hipLaunchKernelGGL(load_rows_kernel, dim3((kIqStride / 4 + 255) / 256, nseg), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(sI), reinterpret_cast<const float4*>(sQ), stride / 4, samples / 4,
+                       reinterpret_cast<float4*>(dI), reinterpret_cast<float4*>(dQ));
+    return true;
+}
+
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st) {
     if (nseg <= 0) return;
     hipLaunchKernelGGL(normalise_kernel, dim3(nseg), dim3(1024), 0, st, dI, dQ, n_valid, n_total);

@@ -125,6 +125,9 @@ void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, c
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
                       unsigned char* data, hipStream_t st);
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
+// resident input rows -> working rows (zero tail); false if the input is not 16-byte friendly
+bool launch_load_rows(const float* sI, const float* sQ, size_t stride, int samples, int nseg, float* dI, float* dQ,
+                      hipStream_t st);
 // Front-end state of one receiver between chunks of its sample stream (all zero at start-up):
 // samples into the open decimation block, both integrators per rail, and the integrator values at
 // the last 36 decimation instants (what the two combs and the 33-tap FIR still need).
