@@ -251,6 +251,26 @@ def test_committed_scene_spots_without_the_oracle(w):
         assert all(abs(a["snr"] - b["snr"]) <= 0.1 for a, b in zip(rec, g["spots"]))
 
 
+def test_non_finite_and_extreme_inputs_terminate(w, ref_iq):
+    """NaN / Inf / overflowing / denormal / all-zero IQ: the decoder must come back (no fault, no endless
+    search); where the input is finite the spots are the oracle's."""
+    I, Q = ref_iq
+    a = I.copy(); a[1000] = np.nan
+    b = I.copy(); b[5000:5100] = np.inf
+    cases = [(a, Q.copy(), False), (b, Q.copy(), False), (np.full_like(I, np.nan), np.full_like(Q, np.nan), False),
+             (np.zeros_like(I), np.zeros_like(Q), True), (I * np.float32(1e30), Q * np.float32(1e30), True),
+             (I * np.float32(1e-42), Q * np.float32(1e-42), True), (I * np.float32(1e-3), Q * np.float32(1e-3), True)]
+    for x, y, finite in cases:
+        spots, _, _ = w.wspr_decode(x, y, NS)
+        if finite:
+            ref, _, _ = ol.decode(x, y, NS)
+            assert [_spot_tuple(s) for s in spots] == [_spot_tuple(s) for s in ref]
+        else:
+            assert len(spots) <= 1
+    # the scaled-down copy still decodes (the decoder is scale-free apart from float range)
+    assert [s.message for s in w.wspr_decode(I * np.float32(1e-3), Q * np.float32(1e-3), NS)[0]] == [b"K1JT FN20 20"]
+
+
 def test_empty_and_degenerate_inputs(w):
     z = np.zeros((2, NS), np.float32)
     assert w.wspr_decode_batch(z, z) == [[], []]
