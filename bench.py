@@ -90,7 +90,7 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
 RAW_BYTES = 576_000_000                      # 120 s x 2.4 Msps x 2 bytes
 
 
-def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0):
+def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0, amp_lsb=None):
     """Config-5 raw segments: unsigned 8-bit interleaved I/Q at 2.4 Msps.  The config-2 baseband
     frame (375 sps) is held for 6400 samples, moved to -600 kHz (the tuner sits fs/4 above the band:
     rtlsdr_wsprd.c:1112; the receiver's (1, j, -1, -j) mixer brings it back), buried in wide-band
@@ -104,7 +104,7 @@ def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0):
     df, dt = 375.0 / 256.0, 1.0 / 375.0
     # in-band noise power in 2500 Hz of complex noise with sigma per rail at 2.4 Msps
     n2500 = 2.0 * noise_lsb ** 2 * 2500.0 / 2.4e6
-    amp = float(np.sqrt(n2500 * 10.0 ** (snr_db / 10.0)))
+    amp = float(np.sqrt(n2500 * 10.0 ** (snr_db / 10.0))) if amp_lsb is None else float(amp_lsb)
     expected = []
     chunk = 6400 * 1500                                   # 9.6 M samples per chunk
     for s in range(nseg):

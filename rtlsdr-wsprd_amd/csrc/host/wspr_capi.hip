@@ -259,8 +259,15 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
 int wspr_fano_batch_device(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
                            unsigned* metric, unsigned* maxnp, unsigned char* data) {
     try {
-        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data);
+        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, true);
     } catch (const std::exception& e) { return fail("wspr_fano_batch_device", e); }
+}
+
+int wspr_fano_batch_device_wave(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
+                                unsigned* metric, unsigned* maxnp, unsigned char* data, unsigned* steps) {
+    try {
+        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, false, steps);
+    } catch (const std::exception& e) { return fail("wspr_fano_batch_device_wave", e); }
 }
 
 int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat, int iters,

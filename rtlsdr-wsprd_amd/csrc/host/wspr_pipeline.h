@@ -87,8 +87,11 @@ public:
                       float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, float* sync,
                       int mode);
     void subtract_single(float* id, float* qd, long np, float f0, int shift, float drift, const unsigned char* sym);
+    // serial_lanes: the one-lane-per-vector kernel (k6_fano_tail.hip; also fills metric/maxnp of time-outs)
+    // instead of the wave-parallel search (k6_fano_wave.hip); steps (may be null): expansion steps per vector
     int fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
-                   unsigned* metric, unsigned* maxnp, unsigned char* data);
+                   unsigned* metric, unsigned* maxnp, unsigned char* data, bool serial_lanes = false,
+                   unsigned* steps = nullptr);
     int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);
     int decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
                         int* h_nout, DecimState* d_states = nullptr);

@@ -155,7 +155,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, streamraw, streamstate;
+        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
@@ -1075,13 +1075,15 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     return 1;
 }
 
-// Device Fano search over n host vectors: interleaved soft symbols in, results out
+// Device Fano search over n host vectors: interleaved soft symbols in, results out.  The wave-parallel
+// kernel reports -2 for a vector whose pending-visit store overflowed (not seen in tests; the serial host
+// decoder takes those).
 int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
-                        unsigned* metric, unsigned* maxnp, unsigned char* data) {
+                        unsigned* metric, unsigned* maxnp, unsigned char* data, bool serial_lanes, unsigned* steps) {
     Impl& c = *d;
     if (n <= 0) return 0;
-    std::vector<int> off(n);
-    for (int i = 0; i < n; ++i) off[i] = i;
+    int* h_off = static_cast<int*>(c.h_misc.need((size_t)n * 4));
+    for (int i = 0; i < n; ++i) h_off[i] = i;
     unsigned char* dsym = static_cast<unsigned char*>(c.fz_sym.need((size_t)n * kNSymD));
     int* doff = static_cast<int*>(c.fz_off.need((size_t)n * 4));
     int* dret = static_cast<int*>(c.fz_ret.need((size_t)n * 4));
@@ -1089,15 +1091,35 @@ int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles,
     unsigned* dmet = static_cast<unsigned*>(c.fz_met.need((size_t)n * 4));
     unsigned* dmax = static_cast<unsigned*>(c.fz_max.need((size_t)n * 4));
     unsigned char* ddat = static_cast<unsigned char*>(c.fz_dat.need((size_t)n * 10));
+    unsigned* dsteps = steps ? static_cast<unsigned*>(c.fz_steps.need((size_t)n * 4)) : nullptr;
     upload(dsym, symbols, (size_t)n * kNSymD, c.stream);
-    upload(doff, off.data(), (size_t)n * 4, c.stream);
-    launch_fano_tail(dsym, doff, n, c.t_metric0.as<short>(), 60, maxcycles, dret, dcyc, dmet, dmax, ddat, c.stream);
+    upload(doff, h_off, (size_t)n * 4, c.stream);
+    if (serial_lanes)
+        launch_fano_tail(dsym, doff, n, c.t_metric0.as<short>(), 60, maxcycles, dret, dcyc, dmet, dmax, ddat, c.stream);
+    else
+        launch_fano_wave(dsym, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, dmet, dmax, ddat, dsteps, c.stream);
     HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(metric, dmet, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(maxnp, dmax, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
+    if (steps) HIP_OK(hipMemcpyAsync(steps, dsteps, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     sync();
+    if (!serial_lanes) {
+        std::vector<int> redo;
+        for (int i = 0; i < n; ++i) if (ret[i] == -2) redo.push_back(i);
+        if (!redo.empty()) {
+            const FanoMetrics& met = default_metrics();
+            c.bigpool->run((int)redo.size(), [&](int k) {
+                const int i = redo[k];
+                unsigned char sym[kNSymD], out11[11] = {0};
+                memcpy(sym, symbols + (size_t)i * kNSymD, kNSymD);
+                deinterleave162(sym);
+                ret[i] = fano_decode(&metric[i], &cycles[i], &maxnp[i], out11, sym, kNBits, met.tab, 60, maxcycles);
+                memcpy(data + (size_t)i * 10, out11, 10);
+            }, 1);
+        }
+    }
     return 0;
 }
 

@@ -481,3 +481,77 @@ def test_device_fano_equals_host_fano(w):
             nto += r != 0
         print("device fano: maxcycles %d, %d vectors, %d time-outs, %.1f ms" % (maxcycles, n, nto, dt * 1e3))
         assert 20 < nto < n - 20
+
+
+def test_wave_fano_equals_host_fano(w):
+    """K6w (fano_wave.h): one wavefront per vector, 64 tree visits per step.  Return code, cycle count
+    and decoded bytes equal the host routine's (= the reference's fano.c) for decodable vectors, early
+    time-outs and full 810 000-cycle time-outs; metric/maxnp for decoded frames."""
+    import time
+    L = w.lib()
+    rng = np.random.default_rng(18)
+    mt = (C.c_int * 256 * 2)(); L.wspr_fano_metric_table(mt)
+    enc = (C.c_ubyte * 176)()
+    vecs = []
+    for t in range(360):
+        data = [int(x) for x in rng.integers(0, 256, 7)] + [0, 0, 0, 0]
+        data[6] &= 0xC0
+        L.encode(enc, (C.c_ubyte * 11)(*data), C.c_uint(11))
+        bits = (C.c_ubyte * 162)(*list(enc)[:162])
+        L.interleave(bits)                                   # transmission order, as the demodulator emits
+        sigma = [5, 25, 40, 50, 55, 60, 65, 75, 100, 150, 400, 1000][t % 12]
+        vecs.append(np.clip(np.where(np.frombuffer(bits, np.uint8) > 0, 178, 78) + rng.normal(0, sigma, 162), 0, 255).astype(np.uint8))
+    vecs += [np.full(162, 128, np.uint8), np.zeros(162, np.uint8), np.full(162, 255, np.uint8),
+             np.tile(np.array([0, 255], np.uint8), 81)]
+    sym = np.stack(vecs)
+    L.wspr_fano_batch_device_wave.argtypes = [C.c_void_p, C.c_int, C.c_uint] + [C.c_void_p] * 6
+    for maxcycles in (50, 200, 1500, 10000):
+        n = sym.shape[0]
+        ret = np.zeros(n, np.int32); cyc = np.zeros(n, np.uint32); met = np.zeros(n, np.uint32); mnp = np.zeros(n, np.uint32)
+        dat = np.zeros((n, 10), np.uint8); steps = np.zeros(n, np.uint32)
+        t0 = time.time()
+        assert L.wspr_fano_batch_device_wave(ol.ptr(sym), n, maxcycles, ol.ptr(ret), ol.ptr(cyc), ol.ptr(met), ol.ptr(mnp),
+                                             ol.ptr(dat), ol.ptr(steps)) == 0
+        dt = time.time() - t0
+        nto = 0
+        for i in range(n):
+            s = (C.c_ubyte * 162)(*sym[i].tolist())
+            L.deinterleave(s)
+            dec = (C.c_ubyte * 11)(); a = C.c_uint(); b = C.c_uint(); c = C.c_uint()
+            r = L.fano(C.byref(a), C.byref(b), C.byref(c), dec, s, C.c_uint(81), mt, C.c_int(60), C.c_uint(maxcycles))
+            assert (ret[i], cyc[i]) == (r, b.value), (i, maxcycles, ret[i], cyc[i], r, b.value)
+            if r == 0:
+                assert (met[i], mnp[i]) == (a.value, c.value) and list(dat[i]) == list(dec)[:10], (i, maxcycles)
+            nto += r != 0
+        print("wave fano: maxcycles %d, %d vectors, %d time-outs, %.1f ms, steps max %d mean %.0f" % (
+            maxcycles, n, nto, dt * 1e3, steps.max(), steps.mean()))
+        assert 20 < nto < n - 20
+
+
+def test_wave_fano_many_time_outs_throughput(w):
+    """The crowded-band tail: thousands of undecodable vectors, full budget.  All time out exactly like
+    the host routine says (sampled), in tens of milliseconds instead of ~5 ms of a CPU core each."""
+    import time
+    L = w.lib()
+    rng = np.random.default_rng(99)
+    n = 6000
+    sym = np.clip(rng.normal(128, 45, (n, 162)), 0, 255).astype(np.uint8)
+    L.wspr_fano_batch_device_wave.argtypes = [C.c_void_p, C.c_int, C.c_uint] + [C.c_void_p] * 6
+    ret = np.zeros(n, np.int32); cyc = np.zeros(n, np.uint32); met = np.zeros(n, np.uint32); mnp = np.zeros(n, np.uint32)
+    dat = np.zeros((n, 10), np.uint8); steps = np.zeros(n, np.uint32)
+    for rep in range(2):
+        t0 = time.time()
+        assert L.wspr_fano_batch_device_wave(ol.ptr(sym), n, 10000, ol.ptr(ret), ol.ptr(cyc), ol.ptr(met), ol.ptr(mnp),
+                                             ol.ptr(dat), ol.ptr(steps)) == 0
+        dt = time.time() - t0
+    print("wave fano: %d noise vectors, full budget: %.1f ms (%d time-outs), steps mean %.0f max %d" % (
+        n, dt * 1e3, int((ret == -1).sum()), steps.mean(), steps.max()))
+    assert (ret != -2).all()
+    mt = (C.c_int * 256 * 2)(); L.wspr_fano_metric_table(mt)
+    for i in range(0, n, 500):
+        s = (C.c_ubyte * 162)(*sym[i].tolist())
+        L.deinterleave(s)
+        dec = (C.c_ubyte * 11)(); a = C.c_uint(); b = C.c_uint(); c = C.c_uint()
+        r = L.fano(C.byref(a), C.byref(b), C.byref(c), dec, s, C.c_uint(81), mt, C.c_int(60), C.c_uint(10000))
+        assert (ret[i], cyc[i]) == (r, b.value)
+    assert dt < 1.0
