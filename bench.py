@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- 2-minute WSPR segments decoded per second on MI355X.
 
-Workload (BASELINE.json configs[1]): 1 024 synthetic "wsprsim" segments per GPU, one
-type-1 signal each at SNR -20 dB (2500 Hz reference bandwidth), 45 000 complex f32
-samples per segment at 375 sps, resident in HBM when the timed region starts.
-A step = one full decode of the batch: FFT bank, peak pick, coarse sync, fine sync,
-soft demodulation (HIP kernels), host Fano decode, coherent subtraction (HIP), second
-pass, spot records on the host.  With --gpus N every rank decodes its own 1 024
-segments (weak scaling) and the spot records are gathered on rank 0 over RCCL.
+Headline workload (BASELINE.json configs[2], the largest single-GPU configuration): 8 192 synthetic
+"wsprsim" segments per GPU, ten overlapping type-1 signals each at SNR -10..-28 dB (2500 Hz reference
+bandwidth), deep search on (reference defaults), 45 000 complex f32 samples per segment at 375 sps,
+resident in HBM when the timed region starts.  A step = one full decode of the batch: FFT bank, peak
+pick, coarse sync, fine sync, soft demodulation (HIP kernels), host Fano decode with the device Fano
+tail, coherent subtraction (HIP), second pass, spot records on the host.  With --gpus N every rank
+decodes its own 8 192 segments (weak scaling) and the spot records are gathered on rank 0 over RCCL.
+--config 2 (configs[1]: 1 024 segments x 1 signal at -20 dB) and --config 5 (configs[4]: raw 2.4 Msps
+u8 IQ through the on-GPU decimator) select the other single-GPU configurations; at N=1 the line also
+carries configs[1] as the block "secondary".
+
+The timed region is never shorter than --min-seconds (default 3 s): if the requested --steps finish
+sooner, the measurement is repeated with proportionally more steps and both numbers are reported.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -146,6 +152,13 @@ def usable_cpus():
     return n
 
 
+K4_FLOP = 33 * 162 * 256 * 32                 # mode-0 lag scan per candidate: 43.8 MFLOP
+K41_FLOP = 5 * 162 * 256 * 32                 # mode-1 frequency scan per candidate: 6.6 MFLOP
+K7_FLOP = 64.3e6                              # subtract_signal2 per decoded signal
+VALU_PEAK_TF = 157.3                          # fp32 vector peak (FMA counted as 2), MI355X_MICROARCH.md
+VALU_NOFMA_TF = 78.6                          # the same pipes issuing separately rounded mul / add
+
+
 def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
     """Oracle (CPU restatement, oracle/liboracle.so) on a bounded sample of the SAME segments."""
     import oracle_lib as ol
@@ -175,15 +188,21 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--segments", type=int, default=None, help="segments per GPU (default: the config's)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
-                    help="BASELINE.json configs index: 2 = configs[1] (1024 seg x 1 signal, -20 dB; the metric's "
-                         "workload), 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB), 5 = configs[4] (raw 2.4 Msps "
-                         "u8 IQ through the on-GPU decimator; --segments raw segments resident per step, default 64)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
+                    help="BASELINE.json configs index: 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB, deep search "
+                         "on; the headline: largest single-GPU configuration), 2 = configs[1] (1024 seg x 1 signal, "
+                         "-20 dB), 5 = configs[4] (raw 2.4 Msps u8 IQ through the on-GPU decimator; --segments raw "
+                         "segments resident per step, default 64)")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
+    ap.add_argument("--fano-fast", type=int, default=None,
+                    help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
+                         "default 200; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight (default 2 when the rank has >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
@@ -201,37 +220,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
-
-    nseg = args.segments or {2: 1024, 3: 8192, 5: 64}[args.config]
     assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
-    if args.config == 2:
-        I, Q, expected = synth_batch_gpu(nseg, 1234 + rank, dev, 1, args.snr, args.snr, 1.0)
-        workload = ("configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr))
-    elif args.config == 3:
-        I, Q, expected = synth_batch_gpu(nseg, 4321 + rank, dev, 10, -10.0, -28.0, 0.3)
-        workload = "configs[2]: %d segments per GPU x 10 overlapping signals, SNR -10..-28 dB, deep search on" % nseg
-        if nseg >= 6144 and "WSPR_FANO_FAST" not in os.environ:
-            # crowded band, thousands of Fano time-outs per step: short host budget + device tail (K6);
-            # results are those of the full budget by construction
-            w.lib().wspr_set_fano_fast_budget(C.c_uint(300))
-            workload += "; Fano budget split 300 cycles/bit on the host pool + device tail"
-    else:
-        raw, expected = synth_raw_gpu(nseg, 777 + rank, dev, args.snr)
-        stride = int(w.lib().wspr_iq_stride())
-        I = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
-        Q = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
-        workload = ("configs[4]: %d raw segments per step (2.4 Msps u8 IQ, 576 MB each, resident in HBM) through the "
-                    "on-GPU decimator (K0) and the decoder; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's "
-                    "4096 segments = %d such resident waves" % (nseg, args.snr, 4096 // nseg))
-    torch.cuda.synchronize()
+    L = w.lib()
+    L.wspr_set_fano_fast_budget.restype = C.c_uint
 
     opt = w.default_options()
     if use_dist:
         opt = wd.broadcast_options(opt, src=0)          # fan-out of the (tiny) job description
-    # Steps are pipelined the way a service would run them: `inflight` batches at a time, each decoded by
-    # its own host thread on its own lane of the library (own streams, buffers, host pools), so that the
-    # serial tail of step k (last slot, result sorting, copies) is covered by the start of step k+1.
-    # Every step is still one complete pass over one batch, and all K timed steps finish inside the fences.
     cpus_here = int(os.environ["WSPR_HOST_THREADS"])
     inflight = args.inflight if args.inflight else (2 if cpus_here >= 6 else 1)
     inflight = max(1, min(inflight, 4))
@@ -240,89 +235,156 @@ def main():
 
     def bind(lane):
         torch.cuda.set_device(local)
-        return w.lib().wspr_bind_thread_lane(lane)
+        return L.wspr_bind_thread_lane(lane)
     for k, ex in enumerate(lanes):
         assert ex.submit(bind, k).result() == k
     rec = C.sizeof(w.decoder_results)
-    decs = [w.BatchDecoder(nseg, max_results=16 if args.config == 2 else 32, options=opt) for _ in range(inflight)]
-    dec = decs[0]
-    gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
-    if args.config == 5:                                  # the decimator's output rows, one set per lane
-        IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
-
-    def decode_on(k):
-        if args.config == 5:
-            Ik, Qk = IQs[k]
-            rc = w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, Ik.data_ptr(), Qk.data_ptr(), 1)
-            assert rc == 0
-            decs[k].decode_ptr(Ik.data_ptr(), Qk.data_ptr(), NS, Ik.stride(0))
-        else:
-            decs[k].decode(I, Q)
-        return k
-
-    def run_steps(n):
-        """n steps, at most `inflight` of them running; spot records are gathered in step order."""
-        pending, last = [], None
-        for s in range(n):
-            done = None
-            if len(pending) >= inflight:
-                done = pending.pop(0).result()
-                if use_dist:
-                    gatherers[done].stage()                   # results copied out: the lane is free again
-            pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
-            if done is not None and use_dist:
-                last = gatherers[done].exchange()             # every rank's records land on rank 0 (RCCL)
-        for fut in pending:
-            k = fut.result()
-            if use_dist:
-                last = gatherers[k].gather()
-        return last
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
-    # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
-    untimed = max(args.warmup, 4 * inflight)
-    run_steps(untimed)
-    fence()
-    t0 = time.perf_counter()
-    gathered = run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def measure(config, nseg, steps, warmup, seed):
+        """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds)."""
+        fast_old = None
+        if config == 2:
+            I, Q, expected = synth_batch_gpu(nseg, 1234 + seed, dev, 1, args.snr, args.snr, 1.0)
+            workload = "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr)
+            raw = None
+        elif config == 3:
+            I, Q, expected = synth_batch_gpu(nseg, 4321 + seed, dev, 10, -10.0, -28.0, 0.3)
+            workload = "configs[2]: %d segments per GPU x 10 overlapping signals, SNR -10..-28 dB, deep search on" % nseg
+            raw = None
+            if nseg >= 1024 and "WSPR_FANO_FAST" not in os.environ:
+                # crowded band, thousands of Fano time-outs per step: short host budget + device tail (K6w);
+                # results are those of the full budget by construction (DESIGN.md section 5)
+                fast = args.fano_fast if args.fano_fast else 200
+                fast_old = L.wspr_set_fano_fast_budget(C.c_uint(fast))
+                workload += "; host Fano budget %d cycles/bit, the rest on the device tail (exact)" % fast
+        else:
+            raw, expected = synth_raw_gpu(nseg, 777 + seed, dev, args.snr)
+            stride = int(L.wspr_iq_stride())
+            I = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
+            Q = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
+            workload = ("configs[4]: %d raw segments per step (2.4 Msps u8 IQ, 576 MB each, resident in HBM) through the "
+                        "on-GPU decimator (K0) and the decoder; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's "
+                        "4096 segments = %d such resident waves" % (nseg, args.snr, 4096 // nseg))
+        torch.cuda.synchronize()
+        decs = [w.BatchDecoder(nseg, max_results=16 if config == 2 else 32, options=opt) for _ in range(inflight)]
+        gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
+        if config == 5:                                  # the decimator's output rows, one set per lane
+            IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
 
-    # correctness of what was timed: every segment's message must be the transmitted one
-    dec = decs[(args.steps - 1) % inflight] if args.steps > 0 else decs[0]      # the last step's results
-    got = [[s.message.decode() for s in dec.spots(i)] for i in range(nseg)]
-    n_sent = sum(len(e) for e in expected)
-    n_ok = sum(len(set(expected[i]) & set(got[i])) for i in range(nseg))
-    n_false = sum(len([m for m in got[i] if m not in expected[i]]) for i in range(nseg))
-    timings = w.last_timings()
+        def decode_on(k):
+            if config == 5:
+                Ik, Qk = IQs[k]
+                rc = L.wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, Ik.data_ptr(), Qk.data_ptr(), 1)
+                assert rc == 0
+                decs[k].decode_ptr(Ik.data_ptr(), Qk.data_ptr(), NS, Ik.stride(0))
+            else:
+                decs[k].decode(I, Q)
+            return k, w.last_timings()                   # timings of THIS step, read on the lane that ran it
+
+        def run_steps(n):
+            """n steps, at most `inflight` of them running; spot records are gathered in step order."""
+            pending, last, tim, lastk = [], None, None, 0
+            for s in range(n):
+                done = None
+                if len(pending) >= inflight:
+                    done, tim = pending.pop(0).result()
+                    if use_dist:
+                        gatherers[done].stage()               # results copied out: the lane is free again
+                pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
+                if done is not None and use_dist:
+                    last = gatherers[done].exchange()         # every rank's records land on rank 0 (RCCL)
+            for fut in pending:
+                lastk, tim = fut.result()
+                if use_dist:
+                    last = gatherers[lastk].gather()
+            return last, tim, lastk
+
+        # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
+        # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
+        untimed = max(warmup, (4 if config == 2 else 1) * inflight)
+        run_steps(untimed)
+
+        def timed(n):
+            fence()
+            t0 = time.perf_counter()
+            out = run_steps(n)
+            fence()
+            el = time.perf_counter() - t0
+            if use_dist:
+                tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            return el, out
+
+        elapsed, (gathered, timings, lastk) = timed(steps)
+        first = {"steps": steps, "seconds": elapsed}
+        n_timed = steps
+        if elapsed < args.min_seconds:
+            # too short to trust: repeat with enough steps for the minimum region (every rank takes the same
+            # decision: `elapsed` is the maximum over ranks)
+            n_timed = int(np.ceil(steps * args.min_seconds / max(elapsed, 1e-6) * 1.1))
+            elapsed, (gathered, timings, lastk) = timed(n_timed)
+        # correctness of what was timed: every segment's message must be the transmitted one
+        dec = decs[lastk]                                                        # the last step's results
+        got = [[s.message.decode() for s in dec.spots(i)] for i in range(nseg)]
+        n_sent = sum(len(e) for e in expected)
+        n_ok = sum(len(set(expected[i]) & set(got[i])) for i in range(nseg))
+        n_false = sum(len([m for m in got[i] if m not in expected[i]]) for i in range(nseg))
+        total_spots = int(gathered[0].sum()) if gathered is not None else dec.total_spots()
+        if fast_old is not None:
+            L.wspr_set_fano_fast_budget(C.c_uint(fast_old))
+        return {"config": config, "nseg": nseg, "I": I, "Q": Q, "raw": raw, "expected": expected, "got": got,
+                "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed,
+                "value": world * nseg * n_timed / elapsed, "ms_per_step": elapsed / n_timed * 1e3,
+                "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
+                "timings": timings}
+
+    nseg = args.segments or {2: 1024, 3: 8192, 5: 64}[args.config]
+    m = measure(args.config, nseg, args.steps, args.warmup, rank)
 
     if rank == 0:
-        total_spots = int(gathered[0].sum()) if gathered is not None else dec.total_spots()
+        I, Q = m["I"], m["Q"]
         # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
         ms = (C.c_double * 8)()
-        w.lib().wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20, C.addressof(ms))
+        L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 5, C.addressof(ms))
         k1, k2, k3 = ms[0], ms[1], ms[2]
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_k1_pmc_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        traffic, traffic_src = None, None
+        for name in ("r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json"):
+            tf = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tf):
+                jd = json.load(open(tf))
+                per_seg = jd.get("hbm_bytes_per_segment") or (jd.get("hbm_bytes_per_launch", 0) / jd.get("segments", 1024))
+                if per_seg:
+                    traffic, traffic_src = per_seg * nseg, "profiles/" + name
+                    break
         roof = {"bound": "hbm", "kernel": "fft_bank_kernel (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic, "avg_launch_ms": k1, "bytes_per_launch": K1_BYTES * nseg,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k1,
+                "bytes_per_launch": K1_BYTES * nseg,
                 "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
                                    "wall_ms": ms[4],
                                    "bytes_per_launch": STAGE_BYTES * nseg,
                                    "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
                                    "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        # ---- the fp32-VALU-bound kernels: tiled lag scan (K4 mode 0), frequency scan + first rung, subtraction (K7)
+        vms = (C.c_double * 8)()
+        L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+        if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 3, C.addressof(vms)) > 0 and vms[2] > 0:
+            def valu(flop_each, n, t_ms):
+                tf = flop_each * n / (t_ms * 1e-3) / 1e12
+                return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
+                        "frac_of_no_fma_bound": tf / VALU_NOFMA_TF}
+            roof["valu"] = {"peak_TFs": VALU_PEAK_TF, "no_fma_bound_TFs": VALU_NOFMA_TF,
+                            "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
+                                    "half the FMA peak",
+                            "K4_lag_scan (demod_tile_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
+                            "K4_freq_scan_first_rung (freq_tile_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
+                            "K7_subtract (sub_runs + sub_ref + sub_filter kernels)": valu(K7_FLOP, vms[3], vms[1])}
         # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
         # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
         if args.config != 5:
@@ -330,14 +392,14 @@ def main():
             src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
             dst = torch.empty_like(src)
             torch.cuda.synchronize()
-            w.lib().wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
+            L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
             t0 = time.perf_counter()
-            w.lib().wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
+            L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
             roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
             del src, dst
         if args.config == 5:
             kms = (C.c_double * 1)()
-            w.lib().wspr_bench_decimate(raw.data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 3, C.addressof(kms))
+            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 3, C.addressof(kms))
             k0_bytes = (RAW_BYTES + 360000) * nseg
             roof["front_end_K0"] = {"bound": "hbm", "avg_launch_ms": kms[0], "bytes_per_launch": k0_bytes,
                                     "achieved_GBs": k0_bytes / (kms[0] * 1e-3) / 1e9,
@@ -346,22 +408,35 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             cnt = min(nseg, 512)
             Ih, Qh = I[:cnt].cpu().numpy(), Q[:cnt].cpu().numpy()
-            cpu, cpu_msgs = cpu_baseline(Ih, Qh, expected[:cnt], 25.0 if args.config == 2 else 60.0)
-            same = sum(1 for i in range(len(cpu_msgs)) if cpu_msgs[i] == got[i])
+            cpu, cpu_msgs = cpu_baseline(Ih, Qh, m["expected"][:cnt], 25.0 if args.config == 2 else 20.0)
+            same = sum(1 for i in range(len(cpu_msgs)) if cpu_msgs[i] == m["got"][i])
             cpu["gpu_equals_cpu_spots"] = "%d/%d segments" % (same, len(cpu_msgs))
+        secondary = None
+        if world == 1 and args.config == 3 and not args.no_secondary and not use_dist:
+            del I, Q
+            m["I"] = m["Q"] = None
+            torch.cuda.empty_cache()
+            m2 = measure(2, 1024, 200, 8, rank)
+            secondary = {"workload": m2["workload"], "value": m2["value"], "unit": "segments/s", "steps": m2["steps"],
+                         "ms_per_step": m2["ms_per_step"], "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
+                         "false_decodes": m2["false_decodes"], "stage_ms_last_step": m2["timings"]}
         out = {
-            "metric": "2-minute WSPR segments decoded per second", "value": world * nseg * args.steps / elapsed,
-            "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
+            "unit": "segments/s", "n_gpus": world, "steps": m["steps"], "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload + ", 45000 complex f32 samples @ 375 sps, resident in HBM; reference "
+            "config": {"workload": m["workload"] + ", 45000 complex f32 samples @ 375 sps, resident in HBM; reference "
                                    "defaults (npasses 2, subtraction on, quickmode off)",
                        "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0",
-                       "batches_in_flight": inflight, "untimed_steps": untimed},
-            "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
-            "stage_ms_last_step": timings, "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
+                       "gathered_over": "rccl" if use_dist else "none (one process)",
+                       "batches_in_flight": inflight, "untimed_steps": m["untimed"]},
+            "steps_requested": args.steps, "seconds_timed": m["elapsed"], "first_try": m["first_try"],
+            "decoded_ok": m["decoded_ok"], "false_decodes": m["false_decodes"], "spots_total": m["spots_total"],
+            "stage_ms_last_step": dict(m["timings"], note="times: maximum over the slots of the lane that ran the last "
+                                                         "step; counts: sum over its slots"),
+            "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
     if use_dist:

@@ -172,6 +172,14 @@ int wspr_last_timings(double *ms, int capacity);
  * pass, ms[4] = wall time of one pass (first launch to last kernel end), all in milliseconds. */
 int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
                         size_t seg_stride, int iters, double *ms);
+/* Times the two fp32-VALU-bound stages on resident data with HIP events on the launch stream: the
+ * strongest candidate of every segment through the tiled lag scan (K4 mode 0, reference wsprd.c:709-719)
+ * and the fused frequency scan + first ladder rung (wsprd.c:721-758), and one coherent subtraction
+ * (K7, wsprd.c:316-413) per segment.  ms must hold 8 doubles: ms[0] = lag scan, ms[1] = subtraction,
+ * ms[2] = candidates, ms[3] = subtraction jobs, ms[4] = frequency scan + first rung (milliseconds per
+ * launch set). */
+int wspr_bench_valu(const void *d_idat, const void *d_qdat, int nseg, int samples, size_t seg_stride,
+                    int iters, double *ms);
 /* Device Fano search (K6) over n soft-symbol vectors of 162 bytes in transmission
  * (interleaved) order, i.e. deinterleave() + fano() of reference wsprd.c:759-761 (fano.c:87-238) with
  * delta 60.  Outputs per vector: ret (0 / -1), cycles, metric, maxnp, data[10].

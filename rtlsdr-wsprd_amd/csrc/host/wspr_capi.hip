@@ -238,6 +238,15 @@ int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int sa
     } catch (const std::exception& e) { return fail("wspr_bench_fft_sync", e); }
 }
 
+int wspr_bench_valu(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,
+                    double* ms) {
+    try {
+        Context& c = Context::get();
+        c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
+        return c.bench_valu(nseg, samples, iters, ms);
+    } catch (const std::exception& e) { return fail("wspr_bench_valu", e); }
+}
+
 int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
     try {
         Context& c = Context::get();

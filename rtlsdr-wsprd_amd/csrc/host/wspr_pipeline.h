@@ -82,6 +82,7 @@ public:
                     const FanoMemo* memo = nullptr);
     int last_timings(double* ms, int cap);
     int bench_fft_sync(int nseg, int samples, int iters, double* ms);
+    int bench_valu(int nseg, int samples, int iters, double* ms);
 
     void demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin, int ifmax,
                       float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, float* sync,

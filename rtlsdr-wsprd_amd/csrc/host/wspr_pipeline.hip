@@ -1049,6 +1049,89 @@ int Context::bench_fft_sync(int nseg, int samples, int iters, double* ms) {
     return 5;
 }
 
+// Kernel-level timing of the two fp32-VALU-bound stages on the resident batch (HIP events on the launch
+// stream): the strongest candidate of every segment goes through the tiled lag scan (K4 mode 0:
+// phasor tables are built before the timed region) and one coherent subtraction (K7) is run per segment
+// at that candidate's coarse parameters.  ms[0] = lag scan, ms[1] = subtraction, ms[2] = candidates,
+// ms[3] = jobs, ms[4] = the frequency scan + first rung (K4 mode 1 fused with K5 rung 0).
+// The working IQ is modified by the subtraction (bench only).
+int Context::bench_valu(int nseg, int samples, int iters, double* ms) {
+    Impl& c = *d;
+    for (int k = 0; k < 5; ++k) ms[k] = 0.0;
+    run_fft_sync(nseg, samples, 4, true, nullptr, nseg, nullptr, nullptr);
+    std::vector<int> npk;
+    std::vector<DevCand> cand;
+    fetch_candidates(nseg, npk, cand);
+    std::vector<FineState> items;
+    std::vector<SubJob> jobs;
+    unsigned char sym[kNSymD];
+    {
+        std::vector<char> hashtab((size_t)kHashSlots * kHashWidth, 0), loctab((size_t)kHashSlots * kLocWidth, 0);
+        char msg[32] = "K1JT FN20 20";
+        if (!channel_symbols(msg, hashtab.data(), loctab.data(), sym)) return -1;
+    }
+    for (int s = 0; s < nseg; ++s) {
+        if (npk[s] <= 0) continue;
+        const DevCand& cd = cand[(size_t)s * kMaxCand];
+        FineState f{};
+        f.seg = s; f.freq = cd.freq; f.drift = 0.0f; f.shift = cd.shift; f.sync = cd.sync;
+        f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
+        items.push_back(f);
+        SubJob jb{};
+        jb.seg = s; jb.f0 = cd.freq; jb.shift = cd.shift; jb.drift = 0.0f;
+        memcpy(jb.sym, sym, kNSymD);
+        jobs.push_back(jb);
+    }
+    const int nw = (int)items.size();
+    if (nw == 0) return 0;
+    std::vector<int> lists(2 * (size_t)nw);
+    int n_shared = 0, n_own = 0;
+    const size_t ntabs = plan_tables(items.data(), nw, lists.data(), &n_shared, &n_own);
+    FineState* d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
+    int* d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
+    float* d_tabs = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)nw * 5) * 2048 * 4));
+    float* d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
+    float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * kMaxLags * 4));
+    unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
+    float* d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
+    float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
+    SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nw * sizeof(SubJob)));
+    float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nw) * 4));
+    HIP_OK(hipMemcpyAsync(d_items, items.data(), (size_t)nw * sizeof(FineState), hipMemcpyHostToDevice, c.stream));
+    HIP_OK(hipMemcpyAsync(d_lists, lists.data(), (size_t)nw * 2 * 4, hipMemcpyHostToDevice, c.stream));
+    HIP_OK(hipMemcpyAsync(dj, jobs.data(), (size_t)nw * sizeof(SubJob), hipMemcpyHostToDevice, c.stream));
+    launch_phasor_tables(d_items, nw, 0, d_tabs, c.stream);
+    HIP_OK(hipStreamSynchronize(c.stream));
+    hipEvent_t e[4];
+    for (auto& x : e) HIP_OK(hipEventCreate(&x));
+    const float* wi = c.iqI.as<float>();
+    const float* wq = c.iqQ.as<float>();
+    for (int it = 0; it < iters; ++it) {
+        HIP_OK(hipEventRecord(e[0], c.stream));
+        launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, 33, 8, 0.0f, d_tabs,
+                           d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
+        HIP_OK(hipEventRecord(e[1], c.stream));
+        launch_pick_lag(d_items, nw, d_sync, 33, 8, c.stream);
+        launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, 8, 0.10f,
+                                        c.t_jitter.as<int>(), d_tabs, d_pw, d_scr, d_sync, d_sym, d_rms, c.tab, c.stream);
+        HIP_OK(hipEventRecord(e[2], c.stream));
+        launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nw, scratch, c.tab, c.stream);
+        HIP_OK(hipEventRecord(e[3], c.stream));
+        HIP_OK(hipEventSynchronize(e[3]));
+        float t = 0;
+        HIP_OK(hipEventElapsedTime(&t, e[0], e[1])); ms[0] += t / iters;
+        HIP_OK(hipEventElapsedTime(&t, e[1], e[2])); ms[4] += t / iters;
+        HIP_OK(hipEventElapsedTime(&t, e[2], e[3])); ms[1] += t / iters;
+        // the frequency scan refined the items: restore the coarse state for the next round
+        HIP_OK(hipMemcpyAsync(d_items, items.data(), (size_t)nw * sizeof(FineState), hipMemcpyHostToDevice, c.stream));
+        launch_phasor_tables(d_items, nw, 0, d_tabs, c.stream);
+        HIP_OK(hipStreamSynchronize(c.stream));
+    }
+    for (auto& x : e) (void)hipEventDestroy(x);
+    ms[2] = nw; ms[3] = nw;
+    return 5;
+}
+
 // average duration of the whole front end (K0 a/b/c + normalise) over `iters` launches
 int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters,
                             double* ms) {
