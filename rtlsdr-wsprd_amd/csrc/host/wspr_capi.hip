@@ -168,7 +168,7 @@ int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samp
         c.load_host(idat, qdat, nseg, samples, seg_stride);
         float* ps = c.ps_buffer(nseg);
         wspr::launch_fft_bank(c.work_i(nseg), c.work_q(nseg), nullptr, nseg, samples, ps, c.tables(), c.stream());
-        std::vector<float> h((size_t)nseg * wspr::kMaxBlocks * wspr::kPsStride);
+        std::vector<float> h((size_t)nseg * wspr::kPsBins * wspr::kPsTPitch);
         HIP_TRY(hipMemcpyAsync(h.data(), ps, h.size() * 4, hipMemcpyDeviceToHost, c.stream()));
         c.sync();
         memset(ps_out, 0, (size_t)nseg * wspr::kFftSize * blocks * sizeof(float));
@@ -176,7 +176,7 @@ int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samp
             for (int t = 0; t < blocks; ++t)
                 for (int b = 0; b < wspr::kPsBins; ++b)
                     ps_out[((size_t)s * wspr::kFftSize + (b + wspr::kPsBin0)) * blocks + t] =
-                        h[((size_t)s * wspr::kMaxBlocks + t) * wspr::kPsStride + b];
+                        h[((size_t)s * wspr::kPsBins + b) * wspr::kPsTPitch + t];
         return blocks;
     } catch (const std::exception& e) { return fail("wspr_stage_fft_bank", e); }
 }

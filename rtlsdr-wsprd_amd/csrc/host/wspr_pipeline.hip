@@ -350,11 +350,13 @@ void Context::sync() {
 }
 
 float* Context::ps_buffer(int nseg) {
-    return static_cast<float*>(d->ps.need((size_t)nseg * kMaxBlocks * kPsStride * 4));
+    return static_cast<float*>(d->ps.need((size_t)nseg * kPsBins * kPsTPitch * 4));
 }
 
 // ---------------------------------------------------------------- stages -----
-// K1 + K2a over `nactive` segments; ev (optional): an event before and after each kernel
+// K1 + K2a over `nactive` segments; ev (optional): an event before and after each kernel.
+// Batches that fill the GPU with one workgroup per segment take the fused kernel (the spectrogram is not
+// read back for the time average); WSPR_K1_FUSED=0/1 forces either form.
 static void fft_and_average(const float* dI, const float* dQ, const int* d_seglist, int nactive, int samples, float* ps,
                             float* psavg, const DeviceTables& tab, hipStream_t st, std::vector<hipEvent_t>* ev = nullptr) {
     const int blocks = 4 * (samples / kFftSize) - 1;
@@ -365,10 +367,13 @@ static void fft_and_average(const float* dI, const float* dQ, const int* d_segli
         HIP_OK(hipEventRecord(e, st));
         ev->push_back(e);
     };
+    static const int fused_cfg = [] { const char* e = getenv("WSPR_K1_FUSED"); return e ? atoi(e) : -1; }();
+    const bool fused = fused_cfg < 0 ? nactive >= 512 : fused_cfg != 0;
     mark();
-    launch_fft_bank(dI, dQ, d_seglist, nactive, samples, ps, tab, st);
+    if (fused) launch_fft_bank_avg(dI, dQ, d_seglist, nactive, samples, ps, psavg, tab, st);
+    else launch_fft_bank(dI, dQ, d_seglist, nactive, samples, ps, tab, st);
     mark(); mark();
-    launch_time_average(ps, d_seglist, nactive, blocks, psavg, st);
+    if (!fused) launch_time_average(ps, d_seglist, nactive, blocks, psavg, st);
     mark();
 }
 

@@ -9,9 +9,15 @@
 //     between passes the 512 points are transposed through a wave-private,
 //     bank-conflict-free LDS tile (row stride 72 / pad 9 complex words).
 //   * consecutive FFTs overlap by 384 samples: a wave walks a run of consecutive
-//     blocks and keeps the raw samples in a sliding register window, so every IQ
-//     sample is fetched from HBM/L2 once per wave (2 coalesced 256-B rows of I and
-//     of Q per FFT) and no LDS staging of the input is needed.
+//     blocks and keeps the raw samples in a sliding register window (2 coalesced
+//     256-B rows of I and of Q fetched per FFT); the four waves of a workgroup walk
+//     adjacent runs, so the overlap between runs is served by the caches.
+//   * output layout is BIN-MAJOR like the reference's ps[512][blocks] (wsprd.c:517):
+//     ps[segment][bin 48..464][time, pitch 352].  The coarse sync reads whole bin rows
+//     (11 per candidate) and the time average walks a bin's row in time order, so both
+//     consumers stream contiguous memory.  A workgroup covers 4 x kRun consecutive
+//     time blocks: the powers are collected in an LDS tile [417 bins][4 kRun] and
+//     written as full 16-byte words, 64/128 contiguous bytes per bin row.
 //   * window and twiddles live in registers for the whole run.
 //   * a complex point is one VGPR pair and every butterfly is written for the packed fp32 pipe
 //     (v_pk_add_f32 / v_pk_mul_f32 with op_sel broadcasts): five instructions per general
@@ -32,6 +38,8 @@ namespace wspr {
 namespace {
 constexpr int kWavesPerWg    = 4;
 constexpr int kTile          = 576;     // complex words of LDS per wave
+// output tile: [417 bins][4 kRun + 1] floats (odd pitch: the 64 bins a wave writes per instruction
+// fall on 32 banks, two lanes each -- the minimum for a 64-wide 4-byte access)
 
 typedef float v2 __attribute__((ext_vector_type(2)));   // (re, im): one VGPR pair, v_pk_*_f32 operands
 
@@ -101,14 +109,14 @@ __device__ __forceinline__ void pass3_last(v2 (&x)[8], float c) {
 
 __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 
-// One FFT of the run: window, 3 passes, power, store.  `raw` is the sliding window of raw
-// samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block instead of
-// moving registers needs the run loop unrolled by 4 (kBase is a compile-time constant).
-template <int kBase>
+// One FFT of the run: window, 3 passes, power into the workgroup's output tile.  `raw` is the sliding
+// window of raw samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block
+// instead of moving registers needs the run loop unrolled by 4 (kBase is a compile-time constant).
+template <int kBase, int kPitch>
 __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], const Tw& twA, const Tw& twB, float w8,
                                         v2* __restrict__ X, int lane, int a, int c,
                                         const float* __restrict__ si, const float* __restrict__ sq, int t, bool more,
-                                        float* __restrict__ out) {
+                                        float* __restrict__ otile, int tl) {
     v2 x[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = raw[(kBase + r) & 7] * win[r];
@@ -139,7 +147,6 @@ __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], con
     pass3_last(x, w8);
 
     // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane)
-    float* __restrict__ row = out + (size_t)t * kPsStride;
     const int lo = (int)rev6((unsigned)lane);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -148,35 +155,113 @@ __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], con
         const int col = bin - kPsBin0;
         if (col >= 0 && col < kPsBins) {
             const v2 e = x[r] * x[r];
-            // streaming store: the spectrogram is far larger than the L2s and is next read by another
-            // kernel (measured: K1 unchanged, the time average that follows 185 -> 143 us per 1024 segments)
-            __builtin_nontemporal_store(e.x + e.y, row + col);
+            otile[col * kPitch + tl] = e.x + e.y;            // 64 lanes -> 64 different bins: 2 lanes per bank
         }
     }
 }
 
-template <int kBlocksPerWave>
+template <int kRun>
 __global__ __launch_bounds__(256)
 void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                      const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
                      const float* __restrict__ window, const float2* __restrict__ twiddle) {
-    __shared__ v2 tile[kWavesPerWg * kTile];
+    extern __shared__ __attribute__((aligned(16))) char k1_smem[];
+    v2* tile = reinterpret_cast<v2*>(k1_smem);                                     // 4 x 576 complex words
+    float* otile = reinterpret_cast<float*>(k1_smem + kWavesPerWg * kTile * sizeof(v2));   // [417][kOutPitch]
+    constexpr int kWgTimes = kWavesPerWg * kRun;
+    constexpr int kOutPitch = kWgTimes + 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
-    const int t_begin = (blockIdx.x * kWavesPerWg + wave) * kBlocksPerWave;
-    if (t_begin >= blocks) return;
-    const int t_end = min(t_begin + kBlocksPerWave, blocks);
+    const int t0 = blockIdx.x * kWgTimes;
+    const int t_begin = t0 + wave * kRun;
+    const int t_end = min(t_begin + kRun, blocks);
 
     const float* __restrict__ si = dI + (size_t)seg * kIqStride;
     const float* __restrict__ sq = dQ + (size_t)seg * kIqStride;
-    float* __restrict__ out = ps + (size_t)seg * kMaxBlocks * kPsStride;
+    v2* X = tile + wave * kTile;
+
+    if (t_begin < t_end) {
+        const int a = lane >> 3, c = lane & 7;
+        float win[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) win[r] = window[64 * r + lane];
+        // pass A: element n = 64 r + lane ; pass B: n = 64 a + 8 r + c ; pass C: n = 8 lane + r
+        Tw twA, twB;
+        set_tw(twA, 0, twiddle[lane]);     set_tw(twA, 1, twiddle[64 + lane]);
+        set_tw(twA, 2, twiddle[128 + lane]); set_tw(twA, 3, twiddle[192 + lane]);
+        set_tw(twA, 4, twiddle[2 * lane]); set_tw(twA, 5, twiddle[128 + 2 * lane]);
+        set_tw(twA, 6, twiddle[4 * lane]);
+        set_tw(twB, 0, twiddle[8 * c]);    set_tw(twB, 1, twiddle[64 + 8 * c]);
+        set_tw(twB, 2, twiddle[128 + 8 * c]); set_tw(twB, 3, twiddle[192 + 8 * c]);
+        set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
+        set_tw(twB, 6, twiddle[32 * c]);
+        const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
+
+        v2 raw[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = kHop * t_begin + 64 * r + lane;
+            raw[r] = v2{si[k], sq[k]};
+        }
+        for (int t = t_begin; t < t_end; t += 4) {
+            one_fft<0, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t, t + 1 < t_end, otile, t - t0);
+            if (t + 1 >= t_end) break;
+            one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 1, t + 2 < t_end, otile, t + 1 - t0);
+            if (t + 2 >= t_end) break;
+            one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 2, t + 3 < t_end, otile, t + 2 - t0);
+            if (t + 3 >= t_end) break;
+            one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 3, t + 4 < t_end, otile, t + 3 - t0);
+        }
+    }
+    __syncthreads();
+
+    // tile -> HBM: bin row b, times t0 .. t0 + kWgTimes - 1 as 16-byte words (8 or 4 per row: 128 or 64
+    // contiguous bytes); streaming stores -- the spectrogram is far larger than the L2s and is next read
+    // by other kernels.  Times beyond `blocks` (padding of the 352-float row) are written as zeros.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int kParts = kWgTimes / 4;
+    float* __restrict__ out = ps + (size_t)seg * kPsBins * kPsTPitch + t0;
+    for (int e = threadIdx.x; e < kPsBins * kParts; e += 256) {
+        const int b = e / kParts, part = e - b * kParts;
+        const int tl = 4 * part;
+        if (t0 + tl >= blocks) continue;
+        const float* __restrict__ src = otile + b * kOutPitch + tl;
+        f4 v;
+        v.x = src[0];
+        v.y = (t0 + tl + 1 < blocks) ? src[1] : 0.0f;
+        v.z = (t0 + tl + 2 < blocks) ? src[2] : 0.0f;
+        v.w = (t0 + tl + 3 < blocks) ? src[3] : 0.0f;
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (size_t)b * kPsTPitch + tl));
+    }
+}
+
+// Fused form for large batches: ONE workgroup walks a whole segment, 16 time blocks (4 per wave) at a
+// time, and folds every finished tile into the segment's time-averaged spectrum (wsprd.c:556-561:
+// psavg[bin] = sum over the time blocks IN ORDER) before the next group starts -- thread = bin, so each
+// running sum is the reference's serial one.  The spectrogram is then never read back for the average:
+// the stage's HBM traffic drops from IQ + 2 x ps to IQ + ps.  A wave's four blocks are consecutive (sliding
+// sample window inside the group); between groups the window is reloaded (the rows come from the caches).
+template <int kRun>
+__global__ __launch_bounds__(256)
+void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
+                         const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
+                         float* __restrict__ psavg, const float* __restrict__ window,
+                         const float2* __restrict__ twiddle) {
+    extern __shared__ __attribute__((aligned(16))) char k1_smem[];
+    v2* tile = reinterpret_cast<v2*>(k1_smem);
+    float* otile = reinterpret_cast<float*>(k1_smem + kWavesPerWg * kTile * sizeof(v2));
+    constexpr int kWgTimes = kWavesPerWg * kRun;
+    constexpr int kOutPitch = kWgTimes + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
+    const float* __restrict__ si = dI + (size_t)seg * kIqStride;
+    const float* __restrict__ sq = dQ + (size_t)seg * kIqStride;
     v2* X = tile + wave * kTile;
 
     const int a = lane >> 3, c = lane & 7;
     float win[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) win[r] = window[64 * r + lane];
-    // pass A: element n = 64 r + lane ; pass B: n = 64 a + 8 r + c ; pass C: n = 8 lane + r
     Tw twA, twB;
     set_tw(twA, 0, twiddle[lane]);     set_tw(twA, 1, twiddle[64 + lane]);
     set_tw(twA, 2, twiddle[128 + lane]); set_tw(twA, 3, twiddle[192 + lane]);
@@ -186,24 +271,66 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
     set_tw(twB, 2, twiddle[128 + 8 * c]); set_tw(twB, 3, twiddle[192 + 8 * c]);
     set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
     set_tw(twB, 6, twiddle[32 * c]);
-    const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
+    const float w8 = twiddle[64].x;
 
-    v2 raw[8];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int kParts = kWgTimes / 4;
+    float* __restrict__ out_seg = ps + (size_t)seg * kPsBins * kPsTPitch;
+    const int b_lo = threadIdx.x, b_hi = threadIdx.x + 256;              // the bins this thread averages
+    float acc_lo = 0.0f, acc_hi = 0.0f;
+
+    for (int t0 = 0; t0 < blocks; t0 += kWgTimes) {
+        const int t_begin = t0 + wave * kRun;
+        const int t_end = min(t_begin + kRun, blocks);
+        if (t_begin < t_end) {
+            v2 raw[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int k = kHop * t_begin + 64 * r + lane;
-        raw[r] = v2{si[k], sq[k]};
+            for (int r = 0; r < 8; ++r) {
+                const int k = kHop * t_begin + 64 * r + lane;
+                raw[r] = v2{si[k], sq[k]};
+            }
+            static_assert(kRun == 4, "the group loop below is written for four blocks per wave");
+            one_fft<0, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin, t_begin + 1 < t_end, otile, t_begin - t0);
+            if (t_begin + 1 < t_end)
+                one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 1, t_begin + 2 < t_end, otile, t_begin + 1 - t0);
+            if (t_begin + 2 < t_end)
+                one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 2, t_begin + 3 < t_end, otile, t_begin + 2 - t0);
+            if (t_begin + 3 < t_end)
+                one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 3, false, otile, t_begin + 3 - t0);
+        }
+        __syncthreads();                                               // the group's tile is complete
+        const int nt = min(kWgTimes, blocks - t0);
+        for (int e = threadIdx.x; e < kPsBins * kParts; e += 256) {
+            const int b = e / kParts, part = e - b * kParts;
+            const int tl = 4 * part;
+            if (tl >= nt) continue;
+            const float* __restrict__ src = otile + b * kOutPitch + tl;
+            f4 v;
+            v.x = src[0];
+            v.y = (tl + 1 < nt) ? src[1] : 0.0f;
+            v.z = (tl + 2 < nt) ? src[2] : 0.0f;
+            v.w = (tl + 3 < nt) ? src[3] : 0.0f;
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out_seg + (size_t)b * kPsTPitch + t0 + tl));
+        }
+        {
+            const float* __restrict__ m0 = otile + b_lo * kOutPitch;
+            const float* __restrict__ m1 = otile + b_hi * kOutPitch;
+            if (nt == kWgTimes) {
+#pragma unroll
+                for (int j = 0; j < kWgTimes; ++j) acc_lo += m0[j];
+                if (b_hi < kPsBins) {
+#pragma unroll
+                    for (int j = 0; j < kWgTimes; ++j) acc_hi += m1[j];
+                }
+            } else {
+                for (int j = 0; j < nt; ++j) acc_lo += m0[j];
+                if (b_hi < kPsBins) for (int j = 0; j < nt; ++j) acc_hi += m1[j];
+            }
+        }
+        __syncthreads();                                               // the tile may be overwritten
     }
-
-    for (int t = t_begin; t < t_end; t += 4) {
-        one_fft<0>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t, t + 1 < t_end, out);
-        if (t + 1 >= t_end) break;
-        one_fft<2>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 1, t + 2 < t_end, out);
-        if (t + 2 >= t_end) break;
-        one_fft<4>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 2, t + 3 < t_end, out);
-        if (t + 3 >= t_end) break;
-        one_fft<6>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 3, t + 4 < t_end, out);
-    }
+    psavg[(size_t)seg * kPsStride + b_lo] = acc_lo;
+    if (b_hi < kPsBins) psavg[(size_t)seg * kPsStride + b_hi] = acc_hi;
 }
 
 }  // namespace
@@ -223,23 +350,39 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
                      int samples, float* ps, const DeviceTables& t, hipStream_t st) {
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (blocks <= 0 || nseg_active <= 0) return;
-    // consecutive FFTs per wave: longer runs re-read less input (run of R blocks loads R+3 hops)
-    static const int bpw = [] { const char* e = getenv("WSPR_K1_BLOCKS_PER_WAVE"); return e ? atoi(e) : 22; }();
+    // consecutive FFTs per wave: 4 (a workgroup covers 16 time blocks: 64-byte row segments, 47 KB of LDS,
+    // three workgroups per CU; measured 259 us per 1024 segments) or 8 (32 time blocks: 128-byte segments,
+    // 73 KB, two per CU; 282 us)
+    static const int run = [] { const char* e = getenv("WSPR_K1_RUN"); return e ? atoi(e) : 4; }();
 #define WSPR_K1(R)                                                                                          \
     do {                                                                                                    \
         const int per_wg = R * kWavesPerWg;                                                                 \
+        const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (per_wg + 1) * sizeof(float); \
+        static const bool once = [&] {                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_bank_kernel<R>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+            return true;                                                                                    \
+        }();                                                                                                \
+        (void)once;                                                                                         \
         dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);                                             \
-        hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), 0, st, dI, dQ, seg_list, blocks, ps,        \
+        hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), lds, st, dI, dQ, seg_list, blocks, ps,      \
                            t.window, t.twiddle);                                                            \
     } while (0)
-    // 347 blocks = 16 waves x 22 (4 full workgroups, 98.6 % of the lanes busy); 16 per wave leaves a sixth
-    // workgroup half empty (0.25 vs 0.234 ms per 1024 segments)
-    if (bpw == 12) WSPR_K1(12);
-    else if (bpw == 8) WSPR_K1(8);
-    else if (bpw == 16) WSPR_K1(16);
-    else if (bpw == 44) WSPR_K1(44);
-    else WSPR_K1(22);
+    if (run == 8) WSPR_K1(8);
+    else WSPR_K1(4);
 #undef WSPR_K1
+}
+
+// K1 + K2a in one kernel (see fft_bank_avg_kernel); one workgroup per segment, so only for batches that
+// fill the GPU on their own.
+void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
+                         int samples, float* ps, float* psavg, const DeviceTables& t, hipStream_t st) {
+    const int blocks = 4 * (samples / kFftSize) - 1;
+    if (blocks <= 0 || nseg_active <= 0) return;
+    constexpr int R = 4;
+    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (R * kWavesPerWg + 1) * sizeof(float);
+    hipLaunchKernelGGL(fft_bank_avg_kernel<R>, dim3(nseg_active), dim3(256), lds, st, dI, dQ, seg_list, blocks, ps,
+                       psavg, t.window, t.twiddle);
 }
 
 }  // namespace wspr

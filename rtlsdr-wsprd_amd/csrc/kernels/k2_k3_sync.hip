@@ -1,48 +1,72 @@
 // K2 -- candidate peak picker, K3 -- coarse (frequency, lag, drift) sync search.
 //
 // K2 replaces reference wsprd/wsprd.c:555-631, K3 replaces :646-678.  Both read
-// the power spectrogram written by K1 and are bound by that read (HBM/L2):
-// 578 796 algorithmic bytes per segment per pass.
+// the bin-major power spectrogram written by K1.  The time average is bound by that read
+// (HBM: 578 796 algorithmic bytes per segment per pass); the coarse sync by its arithmetic
+// (~250 000 separately rounded adds per candidate) once its rows arrive as contiguous lines.
 //
 // Float evaluation order is the reference's: every sum that feeds a threshold or
 // an argmax is accumulated by ONE lane in the reference's loop order; lanes
 // parallelise over independent sums (bins, or (freq, lag, drift) hypotheses).
 #include "wspr_device.h"
 #include <cstdlib>
+#include <stdint.h>
 
 #pragma clang fp contract(off)
 
 namespace wspr {
+const unsigned char* sync_vector();           // host copy of the sync vector (wspr_message.cpp)
 namespace {
 
 constexpr double kHalfDf = 375.0 / 256.0 / 2.0;      // (DF / 2.0), wsprd.c:615
 
 // ------------------------------------------------------------------ K2 ------
-// K2a: time-averaged spectrum.  lane = bin, serial over the 347 time blocks in reference order
-// (wsprd.c:556-561).  Pure streaming read of ps (the HBM-bound part of K2): one wave per 64 bins
-// so that thousands of independent waves keep the memory system busy.
+// K2a: time-averaged spectrum (wsprd.c:556-561: psavg[bin] = sum over the time blocks, in block order).
+// One wave per 64 bins.  A bin's row is contiguous in HBM (bin-major spectrogram), so the wave streams
+// 64 rows x 128 bytes per chunk with 16-byte loads (8 lanes per row), parks the chunk in LDS and each
+// lane then adds ITS bin's 32 values in time order -- the reference's serial sum, fully coalesced.
+// The next chunk's loads are in flight while the current one is summed.
+constexpr int kAvgPitch = 33;
 __global__ __launch_bounds__(64)
 void time_average_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
                          float* __restrict__ psavg) {
-    const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
-    const int col = 4 * (blockIdx.x * 64 + threadIdx.x);          // 4 bins (16 B) per lane
-    if (col >= kPsBins) return;                                     // columns 417..431 of a row are padding
+    __shared__ float tile[64 * kAvgPitch];
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4* __restrict__ P = reinterpret_cast<const f4*>(ps + (size_t)seg * kMaxBlocks * kPsStride + col);
-    constexpr int kRow4 = kPsStride / 4;
-    // four independent serial chains per lane; batch the loads ahead of the adds
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    constexpr int kUnroll = 8;
-    int t = 0;
-    for (; t + kUnroll <= blocks; t += kUnroll) {
-        f4 v[kUnroll];
+    const int seg = seg_list ? seg_list[blockIdx.y] : (int)blockIdx.y;
+    const int lane = threadIdx.x, b0 = blockIdx.x * 64;
+    const int nb = min(64, kPsBins - b0);
+    const int part = lane & 7, rsub = lane >> 3;
+    const float* __restrict__ P = ps + ((size_t)seg * kPsBins + b0) * kPsTPitch + 4 * part;
+    const int nchunks = (blocks + 31) / 32;
+    f4 v[8];
+    auto fetch = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = P[(size_t)(t + u) * kRow4];
+        for (int i = 0; i < 8; ++i) {
+            const int row = rsub + 8 * i;
+            v[i] = (row < nb) ? *reinterpret_cast<const f4*>(P + (size_t)row * kPsTPitch + 32 * c) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    float acc = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        for (int i = 0; i < 8; ++i) {
+            float* t = tile + (rsub + 8 * i) * kAvgPitch + 4 * part;
+            t[0] = v[i].x; t[1] = v[i].y; t[2] = v[i].z; t[3] = v[i].w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < nchunks) fetch(c + 1);
+        const int nt = min(32, blocks - 32 * c);
+        const float* __restrict__ mine = tile + lane * kAvgPitch;
+        if (nt == 32) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc += mine[j];
+        } else {
+            for (int j = 0; j < nt; ++j) acc += mine[j];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    for (; t < blocks; ++t) { const f4 v = P[(size_t)t * kRow4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-    *reinterpret_cast<float4*>(psavg + (size_t)seg * kPsStride + col) = acc;
+    if (lane < nb) psavg[(size_t)seg * kPsStride + b0 + lane] = acc;
 }
 
 // K2b: one workgroup per segment, everything after the time average (wsprd.c:565-631)
@@ -155,115 +179,204 @@ void pick_peaks_kernel(const float* __restrict__ psavg, const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------ K3 ------
-// One workgroup per (segment, candidate); lane = one (frequency bin, lag, drift
-// pattern) hypothesis, accumulating its 162-term sums in symbol order.
+// Coarse (frequency, lag, drift) search, wsprd.c:646-678: per candidate 3 frequency bins x 32 lags x
+// (2 maxdrift + 1) drifts, each a 162-term serial float sum of sqrt(ps) values.
 //
 // Reference quirks reproduced:
-//  * "/ DF" expands to "/375.0/256.0", so the per-symbol drift offset only ever
-//    lowers the bin by one for (k>81, drift<0) or (k<81, drift>0): three distinct
-//    patterns; with a strict '>' the first drift of each sign wins, i.e. the label
-//    is -maxdrift, 0 or +1.
-//  * a negative time index reads the previous bin's row, 347+index.
-constexpr int kCoarseRows = 11;
-constexpr int kCoarsePitch = 352;
+//  * "/ DF" expands to "/375.0/256.0", so the per-symbol drift offset only ever lowers the bin by one,
+//    for (k > 81, drift < 0) or (k < 81, drift > 0): three distinct patterns; with a strict '>' the
+//    first drift of each sign wins, i.e. the label is -maxdrift, 0 or +1.
+//  * a negative time index reads the previous bin's row, 347 + index.
+//
+// Mapping: one workgroup = two candidates x three waves; wave = frequency bin ifr, lane = (candidate,
+// lag).  The 11 bin rows a candidate can touch (bins if0-6 .. if0+4, contiguous 1408-byte rows of the
+// bin-major spectrogram) are staged once as sqrt(ps) in LDS with 16-byte loads.  A lane then walks the
+// 162 symbols once for the THREE drift patterns of its (frequency, lag): the eight amplitudes it reads
+// per symbol serve all three, and the patterns share their history -- up to symbol 80 a pattern's sums
+// depend only on the bin it reads (ifr for drift <= 0, ifr-1 for drift > 0), so two running sums stand
+// for the three and fan out at symbol 81.  Every sum is accumulated term by term in the reference's
+// order; two independent sums share one packed-fp32 instruction (each half an ordinary IEEE add).
+constexpr int kCsRows = 11;
+constexpr int kCsPitch = kPsTPitch;
+constexpr int kCsThreads = 192;
+typedef float cs2 __attribute__((ext_vector_type(2)));
+struct SyncBits { uint32_t w[6]; };          // the 162-bit sync vector (wsprd.c:84-93), bit k of word k/32
 
-__global__ __launch_bounds__(320)
+template <bool kFull>
+__global__ __launch_bounds__(kCsThreads)
 void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list, int blocks,
-                        DevCand* __restrict__ cand, const int* __restrict__ npk, int maxdrift,
-                        const unsigned char* __restrict__ pr3) {
-    __shared__ float amp[kCoarseRows * kCoarsePitch];
-    __shared__ float res[288];
-    __shared__ float best_s;
-    __shared__ int arg_s;
-    const int tid = threadIdx.x;
+                        DevCand* __restrict__ cand, const int* __restrict__ npk, int maxdrift, const SyncBits pr3) {
+    __shared__ __attribute__((aligned(16))) float amp[2][kCsRows * kCsPitch];
+    __shared__ float res_best[2][3];
+    __shared__ int res_arg[2][3];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, fi = tid >> 6, lane = tid & 63, half = lane >> 5, k0 = (lane & 31) - 10;
     const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
-    const float* __restrict__ P = ps + (size_t)seg * kMaxBlocks * kPsStride;
-    const int ncand = npk[seg];
+    const float* __restrict__ P = ps + (size_t)seg * kPsBins * kPsTPitch;
+    const int ncand = min(npk[seg], kMaxCand);
     const int npat = (maxdrift > 0) ? 3 : 1;
-    const int nhyp = 3 * 32 * npat;
+    constexpr int kWords = kCsRows * (kCsPitch / 4);              // 968 16-byte words per candidate, rows contiguous
+    constexpr int kPerThread = (2 * kWords + kCsThreads - 1) / kCsThreads;   // 11
+    // the sync bits in six scalar registers (indexing the argument struct dynamically would become a memory
+    // load whose wait also drains the LDS queue)
+    const uint32_t w0 = pr3.w[0], w1 = pr3.w[1], w2 = pr3.w[2], w3 = pr3.w[3], w4 = pr3.w[4], w5 = pr3.w[5];
 
-    for (int c = blockIdx.y; c < ncand; c += gridDim.y) {
-        DevCand cd = cand[(size_t)seg * kMaxCand + c];
-        const int if0 = (int)((double)cd.freq / kHalfDf + 256.0);
-        const int col0 = if0 - 6 - kPsBin0;            // first staged column
-        __syncthreads();
-        // stage sqrt(ps) for the 11 columns this candidate can touch; loads are issued in batches
-        // of 4 so that their latencies overlap
-        const int total = kCoarseRows * blocks;
-        for (int e0 = tid; e0 < total; e0 += 4 * (int)blockDim.x) {
-            float v[4];
+    for (int pair = blockIdx.y; 2 * pair < ncand; pair += gridDim.y) {
+        __syncthreads();                                 // the previous pair's reads are done
+        // ---- stage sqrt(ps) of both candidates' bin rows: every load of the pair in flight at once ----
+        const int c_a = 2 * pair, c_b = 2 * pair + 1;
+        const int if0_a = (int)((double)cand[(size_t)seg * kMaxCand + c_a].freq / kHalfDf + 256.0);
+        const int if0_b = (c_b < ncand) ? (int)((double)cand[(size_t)seg * kMaxCand + c_b].freq / kHalfDf + 256.0) : if0_a;
+        const float* __restrict__ src_a = P + (size_t)(if0_a - 6 - kPsBin0) * kPsTPitch;
+        const float* __restrict__ src_b = P + (size_t)(if0_b - 6 - kPsBin0) * kPsTPitch;
+        f4 v[kPerThread];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                const int t = e / kCoarseRows, r = e - t * kCoarseRows;
-                v[u] = (e < total) ? P[(size_t)t * kPsStride + col0 + r] : 0.0f;
-            }
+        for (int u = 0; u < kPerThread; ++u) {
+            const int e = min(tid + kCsThreads * u, 2 * kWords - 1);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>((e < kWords ? src_a + 4 * e : src_b + 4 * (e - kWords))));
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                const int t = e / kCoarseRows, r = e - t * kCoarseRows;
-                if (e < total) amp[r * kCoarsePitch + t] = sqrtf(v[u]);
+        for (int u = 0; u < kPerThread; ++u) {
+            const int e = tid + kCsThreads * u;
+            if (e < 2 * kWords) {
+                f4 r;
+                r.x = sqrtf(v[u].x); r.y = sqrtf(v[u].y); r.z = sqrtf(v[u].z); r.w = sqrtf(v[u].w);
+                *reinterpret_cast<f4*>(&amp[0][0] + 4 * e) = r;             // amp[1] follows amp[0]
             }
         }
         __syncthreads();
 
-        if (tid < nhyp) {
-            const int fi = tid / (32 * npat);
-            const int rem = tid - fi * 32 * npat;
-            const int k0 = rem / npat - 10;
-            const int pat = (npat == 3) ? rem % 3 : 1;     // 0: drift<0, 1: drift 0, 2: drift>0
-            const int ifr = if0 - 1 + fi;
-            float ss = 0.0f, pw = 0.0f;
-            bool any = false;
-#pragma unroll 6
-            for (int k = 0; k < kNSymD; ++k) {
-                const int low = (pat == 0 && k > 81) || (pat == 2 && k < 81);
-                const int ifd = ifr - low;
-                int kidx = k0 + 2 * k;
-                if (kidx < blocks) {
-                    int row = ifd - 3 - (if0 - 6);
-                    if (kidx < 0) { row -= 1; kidx += blocks; }   // previous row of the flat array
-                    const float* a = amp + row * kCoarsePitch + kidx;
-                    const float p0 = a[0], p1 = a[2 * kCoarsePitch], p2 = a[4 * kCoarsePitch], p3 = a[6 * kCoarsePitch];
-                    const float m = (p1 + p3) - (p0 + p2);
-                    ss = pr3[k] ? ss + m : ss - m;
-                    pw = pw + p0 + p1 + p2 + p3;
-                    any = true;
-                }
-            }
-            res[tid] = any ? ss / pw : __int_as_float(0x7fc00000);
-        }
-        __syncthreads();
-        // first hypothesis (in the reference's loop order) with the strictly largest metric:
-        // max by value, ties to the lowest index -- an order-independent reduction
-        if (tid < 64) {
-            float best = -1e30f;
-            int arg = -1;
-            for (int h = tid; h < nhyp; h += 64)
-                if (res[h] > best) { best = res[h]; arg = h; }       // ascending h: keeps the first
+        const int c = 2 * pair + half;
+        // this wave: ifr = if0 - 1 + fi.  Bin "lo" = ifr - 1 (tones in staged rows fi+1, +3, +5, +7), bin
+        // "hi" = ifr (rows fi+2, +4, +6, +8); a[q] below = staged row fi + 1 + q, so (a[2t], a[2t+1]) is tone
+        // t of (lo, hi) -- the natural operand pair of the packed adds.
+        const float* __restrict__ A = amp[half] + (fi + 1) * kCsPitch + k0;
+        auto load_any = [&](int k, float (&a)[8]) {              // any symbol (negative time index, short record)
+            const int kidx = k0 + 2 * k;
+            int off = 2 * k;
+            if (kidx < 0) off += blocks - kCsPitch;              // previous bin's row, 347 + index (Q2)
+            if (!kFull && kidx >= blocks) off = -k0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oa = __shfl_xor(arg, o);
-                const bool take = (oa >= 0) && (arg < 0 || ob > best || (ob == best && oa < arg));
-                if (take) { best = ob; arg = oa; }
-            }
-            if (tid == 0) { best_s = best; arg_s = arg; }
+            for (int q = 0; q < 8; ++q) a[q] = A[q * kCsPitch + off];
+        };
+        // Even and odd symbols read through two base pointers the compiler cannot relate: otherwise it fuses the
+        // loads of symbols k and k+1 (two dwords apart) into ds_read2_b32 pairs, whose halves then have to be
+        // shuffled into the (lo, hi) operand pairs with a dozen moves per step.
+        int odd_off = 2;
+        asm volatile("" : "+v"(odd_off));
+        auto load = [&](int k, float (&a)[8]) {                  // symbols >= 5: the time index is never negative
+            if (!kFull) { load_any(k, a); return; }
+            const int off = (k & 1) ? odd_off + 2 * (k - 1) : 2 * k;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = A[q * kCsPitch + off];
+        };
+        // sync-vector sign as a scalar float (wave-uniform: no vector select)
+        auto sign_of = [&](int k) {
+            const uint32_t w = k < 96 ? (k < 32 ? w0 : (k < 64 ? w1 : w2)) : (k < 128 ? w3 : (k < 160 ? w4 : w5));
+            return __int_as_float(__builtin_amdgcn_readfirstlane((int)(((w >> (k & 31)) & 1u) ? 0x3f800000u : 0xbf800000u)));
+        };
+        // halves: .x = bin lo, .y = bin hi
+        cs2 S = {0.f, 0.f}, W = {0.f, 0.f};
+        auto step1 = [&](int k, const float (&a)[8]) {
+            const float sg = sign_of(k);
+            const cs2 P0 = {a[0], a[1]}, P1 = {a[2], a[3]}, P2 = {a[4], a[5]}, P3 = {a[6], a[7]};
+            const cs2 m = ((P1 + P3) - (P0 + P2)) * sg;          // (p1 + p3) - (p0 + p2), signed by the sync vector
+            const cs2 nS = S + m;
+            const cs2 nW = (((W + P0) + P1) + P2) + P3;
+            if (kFull || k0 + 2 * k < blocks) { S = nS; W = nW; }
+        };
+        // symbols 0..80, the next symbol's amplitudes in flight while the current one is folded in
+        float a0[8], a1[8];
+        load_any(0, a0);
+#pragma unroll
+        for (int k = 0; k < 6; k += 2) {                         // 0..5: lags < 0 still reach before the record
+            load_any(k + 1, a1);
+            step1(k, a0);
+            load_any(k + 2, a0);
+            step1(k + 1, a1);
         }
+        for (int k = 6; k < 80; k += 2) {
+            load(k + 1, a1);
+            step1(k, a0);
+            load(k + 2, a0);
+            step1(k + 1, a1);
+        }
+        load(81, a1);
+        step1(80, a0);
+        // fan out at symbol 81.  U = (pattern 0, pattern 2): pattern 0 (drift < 0) continues bin hi's history
+        // and reads bin hi at symbol 81, bin lo after it; pattern 2 (drift > 0) continues bin lo's history and
+        // reads bin hi from 81 on.  V = pattern 1 (no drift): bin hi throughout.
+        cs2 SU = {S.y, S.x}, WU = {W.y, W.x};
+        float SV = S.y, WV = W.y;
+        {   // symbol 81: all three read bin hi
+            const float sg = sign_of(81);
+            const cs2 P0 = {a1[0], a1[1]}, P1 = {a1[2], a1[3]}, P2 = {a1[4], a1[5]}, P3 = {a1[6], a1[7]};
+            const cs2 m = ((P1 + P3) - (P0 + P2)) * sg;
+            const cs2 nSU = SU + m.y;
+            const cs2 nWU = (((WU + P0.y) + P1.y) + P2.y) + P3.y;
+            const float nSV = SV + m.y;
+            const float nWV = (((WV + P0.y) + P1.y) + P2.y) + P3.y;
+            if (kFull || k0 + 2 * 81 < blocks) { SU = nSU; WU = nWU; SV = nSV; WV = nWV; }
+        }
+        auto step2 = [&](int k, const float (&a)[8]) {           // symbols 82..161: U reads (lo, hi), V reads hi
+            const float sg = sign_of(k);
+            const cs2 P0 = {a[0], a[1]}, P1 = {a[2], a[3]}, P2 = {a[4], a[5]}, P3 = {a[6], a[7]};
+            const cs2 m = ((P1 + P3) - (P0 + P2)) * sg;
+            const cs2 nSU = SU + m;
+            const cs2 nWU = (((WU + P0) + P1) + P2) + P3;
+            const float nSV = SV + m.y;
+            const float nWV = (((WV + P0.y) + P1.y) + P2.y) + P3.y;
+            if (kFull || k0 + 2 * k < blocks) { SU = nSU; WU = nWU; SV = nSV; WV = nWV; }
+        };
+        load(82, a0);
+        for (int k = 82; k < kNSymD; k += 2) {               // 82 .. 161
+            load(k + 1, a1);
+            step2(k, a0);
+            if (k + 2 < kNSymD) load(k + 2, a0);
+            step2(k + 1, a1);
+        }
+        // ---- first hypothesis (in the reference's loop order) with the strictly largest metric ------
+        float best = -1e30f;
+        int arg = -1;
+        {
+            const float r0 = SU.x / WU.x, r1 = SV / WV, r2 = SU.y / WU.y;
+            const int hb = fi * 32 * npat + (k0 + 10) * npat;
+            if (npat == 3) {
+                if (r0 > best) { best = r0; arg = hb; }
+                if (r1 > best) { best = r1; arg = hb + 1; }
+                if (r2 > best) { best = r2; arg = hb + 2; }
+            } else {
+                if (r1 > best) { best = r1; arg = hb; }
+            }
+        }
+        if (c >= ncand) { best = -1e30f; arg = -1; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {               // within the candidate's 32 lanes
+            const float ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            const bool take = (oa >= 0) && (arg < 0 || ob > best || (ob == best && oa < arg));
+            if (take) { best = ob; arg = oa; }
+        }
+        if ((lane & 31) == 0) { res_best[half][fi] = best; res_arg[half][fi] = arg; }
         __syncthreads();
-        if (tid == 0) {
-            const float best = best_s;
-            const int arg = arg_s;
-            if (arg >= 0) {
-                const int fi = arg / (32 * npat);
-                const int rem = arg - fi * 32 * npat;
-                const int k0 = rem / npat - 10;
+        if (tid < 2) {                                   // one lane per candidate: the three frequency bins in order
+            const int cc = 2 * pair + tid;
+            float b = -1e30f;
+            int ar = -1;
+            for (int f = 0; f < 3; ++f)
+                if (res_arg[tid][f] >= 0 && (ar < 0 || res_best[tid][f] > b)) { b = res_best[tid][f]; ar = res_arg[tid][f]; }
+            if (cc < ncand && ar >= 0) {
+                DevCand cd = cand[(size_t)seg * kMaxCand + cc];
+                const int i0 = tid ? if0_b : if0_a;
+                const int f = ar / (32 * npat);
+                const int rem = ar - f * 32 * npat;
+                const int kk = rem / npat - 10;
                 const int pat = (npat == 3) ? rem % 3 : 1;
-                cd.shift = 128 * (k0 + 1);
+                cd.shift = 128 * (kk + 1);
                 cd.drift = (pat == 0) ? (float)(-maxdrift) : (pat == 2 ? 1.0f : 0.0f);
-                cd.freq  = (float)((double)(if0 - 1 + fi - 256) * kHalfDf);
-                cd.sync  = best;
-                cand[(size_t)seg * kMaxCand + c] = cd;
+                cd.freq  = (float)((double)(i0 - 1 + f - 256) * kHalfDf);
+                cd.sync  = b;
+                cand[(size_t)seg * kMaxCand + cc] = cd;
             }
         }
     }
@@ -273,7 +386,7 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
 void launch_time_average(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
                          hipStream_t st) {
     if (nseg_active <= 0) return;
-    hipLaunchKernelGGL(time_average_kernel, dim3((kPsBins + 255) / 256, nseg_active), dim3(64), 0, st, ps, seg_list,
+    hipLaunchKernelGGL(time_average_kernel, dim3((kPsBins + 63) / 64, nseg_active), dim3(64), 0, st, ps, seg_list,
                        blocks, psavg);
 }
 
@@ -290,8 +403,19 @@ void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, i
                         DevCand* cand, const int* npk, int maxdrift,
                         const DeviceTables& t, hipStream_t st) {
     if (nseg_active <= 0) return;
-    hipLaunchKernelGGL(coarse_sync_kernel, dim3(nseg_active, 8), dim3(320), 0, st, ps, seg_list, blocks,
-                       cand, npk, maxdrift, t.sync);
+    static const SyncBits bits = [] {
+        SyncBits b{};
+        const unsigned char* pr3 = sync_vector();
+        for (int k = 0; k < kNSymD; ++k) if (pr3[k]) b.w[k >> 5] |= 1u << (k & 31);
+        return b;
+    }();
+    static const int gy = [] { const char* e = getenv("WSPR_K3_GRID_Y"); return e ? atoi(e) : 16; }();
+    if (blocks == kMaxBlocks)
+        hipLaunchKernelGGL(coarse_sync_kernel<true>, dim3(nseg_active, gy), dim3(kCsThreads), 0, st, ps, seg_list, blocks,
+                           cand, npk, maxdrift, bits);
+    else
+        hipLaunchKernelGGL(coarse_sync_kernel<false>, dim3(nseg_active, gy), dim3(kCsThreads), 0, st, ps, seg_list, blocks,
+                           cand, npk, maxdrift, bits);
 }
 
 }  // namespace wspr

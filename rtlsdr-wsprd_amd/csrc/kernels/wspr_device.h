@@ -3,8 +3,9 @@
 // HBM layout (all float32 unless noted), sized for thousands of resident
 // 2-minute segments (one segment = 45 000 complex samples at 375 sps):
 //   iq      I[nseg][kIqStride], Q[nseg][kIqStride]   planar, rows 256-B aligned
-//   ps      [nseg][blocks<=347][kPsStride]           |X|^2, bin-contiguous rows,
-//                                                     column b = fft-shifted bin 48+b
+//   ps      [nseg][417 bins][kPsTPitch]               |X|^2, bin-major like the reference's
+//                                                     ps[512][blocks]: row b = fft-shifted bin 48+b,
+//                                                     its time blocks contiguous (pitch 352 floats)
 //   cand    DevCand[nseg][200] + npk[nseg]            peak list, strongest first
 // Everything a kernel needs besides these is a small constant table uploaded once
 // (window, twiddles, sync vector, subtraction low-pass taps).
@@ -21,7 +22,9 @@ constexpr int kHop        = 128;
 constexpr int kMaxBlocks  = 347;        // 4*floor(45000/512) - 1
 constexpr int kPsBin0     = 48;         // first fft-shifted bin kept
 constexpr int kPsBins     = 417;        // bins 48..464 (all that any consumer reads)
-constexpr int kPsStride   = 432;        // floats per (segment, time) row
+constexpr int kPsStride   = 432;        // floats per segment of the time-averaged spectrum (psavg)
+constexpr int kPsTPitch   = 352;        // floats per (segment, bin) row of the spectrogram: 347 time blocks + padding
+                                        // (1408 bytes = 11 x 128: every row starts on a 128-byte line)
 constexpr int kSmooth     = 411;        // smoothed-spectrum length
 constexpr int kMaxCand    = 200;
 constexpr int kNSymD      = 162;
@@ -75,6 +78,9 @@ struct DeviceTables {
 // ---- launchers (all asynchronous on `st`) ----------------------------------
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                      int samples, float* ps, const DeviceTables& t, hipStream_t st);
+// K1 fused with the time average (one workgroup per segment): ps as above, psavg[seg][kPsStride]
+void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
+                         int samples, float* ps, float* psavg, const DeviceTables& t, hipStream_t st);
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
 // psavg: scratch, nseg * kPsStride floats (time-averaged spectrum per segment)
 // K2a alone: psavg[seg][kPsStride] = sum over time blocks of ps, in block order (wsprd.c:556-561)
