@@ -63,15 +63,20 @@ struct decoder_results {            /* 80 bytes: the spot record */
 /* Replaces wspr_decode(), reference wsprd/wsprd.h:106-111 / wsprd/wsprd.c:416.
  * Same contract: idat/qdat (length `samples`, <= 45000) are overwritten with the
  * residual after coherent subtraction, decodes[0..*n_results) is filled strongest
- * first, returns 0.  One call = a batch of one segment on the GPU.
- * hashtable.txt / fftw_wisdom.dat side effects of the reference are not kept. */
+ * first, returns 0 (a negative value, with a message on stderr, only if no HIP device is usable: there
+ * is no CPU fallback).  One call = a batch of one segment on the GPU.  With options.usehashtable the
+ * reference's hashtable.txt side effect is kept (read before, written after the decode, wsprd.c:481-494,
+ * 842-852); fftw_wisdom.dat is not (there is no FFTW). */
 int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options options,
                 struct decoder_results *decodes, int *n_results);
 
 /* Batched form of the same call (build-defined): nseg independent
  * segments, planar host buffers idat/qdat[s*seg_stride + i]; results for segment s
- * go to decodes[s*max_results ...], n_results[s].  Inputs are not modified unless
- * writeback != 0. */
+ * go to decodes[s*max_results ...], n_results[s]: a segment's unique spots are ranked by SNR first and
+ * the strongest max_results are returned (the reference allows 100, its caller holds 50).  Inputs are not
+ * modified unless writeback != 0.  options.usehashtable must be 0 when nseg > 1: the hash memory orders
+ * the segments and a batch decodes them concurrently -- such a call is refused with -2 (all n_results 0,
+ * message on stderr), never silently decoded without the option. */
 int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results *decodes,
                       int max_results, int *n_results, int writeback);
@@ -193,6 +198,13 @@ int wspr_fano_batch_device(const unsigned char *symbols, int n, unsigned maxcycl
 int wspr_fano_batch_device_wave(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
                                 unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data,
                                 unsigned *steps);
+/* Devices.  A host thread decodes on the HIP device that is current for it; wspr_set_device() makes
+ * `device` current for the calling thread (0 on success, -1 if there is no such device).  The library keeps
+ * separate contexts (streams, buffers, host pools) per device, so one process can drive all GPUs of a node
+ * with one host thread (or one per lane) per device, segments split by the caller -- no collective is
+ * involved. */
+int wspr_device_count(void);
+int wspr_set_device(int device);
 /* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to four
  * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
  * this (returns the lane actually bound, 0..3); calls made from threads bound to different lanes may
@@ -202,8 +214,8 @@ int wspr_bind_thread_lane(int lane);
  * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with
  * the reference's 10000, and a segment in which one of those decodes after all is decoded again with
  * the full budget everywhere, so results never depend on this value.  Default 10000 = split off
- * (env WSPR_FANO_FAST overrides); 600 pays once a batch carries thousands of Fano time-outs, K6's
- * latency being 0.54 s whatever their number.  Returns the previous value. */
+ * (env WSPR_FANO_FAST overrides); a few hundred pays once a batch carries thousands of Fano time-outs (the
+ * device tail then takes tens of milliseconds for all of them).  Returns the previous value. */
 unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
 /* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
  * ms[0] = average milliseconds per launch. */

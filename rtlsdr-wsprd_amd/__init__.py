@@ -137,7 +137,7 @@ def wspr_decode(idat, qdat, samples=None, options=None):
     return [out[i] for i in range(nres.value)], I, Q
 
 
-def wspr_decode_batch(I, Q, options=None, max_results=16):
+def wspr_decode_batch(I, Q, options=None, max_results=50):
     """Host arrays [nseg, samples] -> list of spot lists."""
     I = np.ascontiguousarray(I, dtype=np.float32)
     Q = np.ascontiguousarray(Q, dtype=np.float32)
@@ -147,7 +147,7 @@ def wspr_decode_batch(I, Q, options=None, max_results=16):
     rc = lib().wspr_decode_batch(_ptr(I), _ptr(Q), nseg, samples, samples, options or default_options(),
                                  C.addressof(out), max_results, C.addressof(nres), 0)
     if rc < 0:
-        raise RuntimeError("wspr_decode_batch failed (no usable HIP device?)")
+        raise RuntimeError("wspr_decode_batch failed (rc %d: no usable HIP device, or usehashtable on a batch)" % rc)
     return [[out[s * max_results + i] for i in range(nres[s])] for s in range(nseg)]
 
 

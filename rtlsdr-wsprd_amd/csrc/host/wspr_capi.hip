@@ -28,6 +28,24 @@ int fail(const char* where, const std::exception& e) {
     fprintf(stderr, "libwspr_mi355x: %s failed: %s\n", where, e.what());
     return -1;
 }
+// The callsign hash memory makes a segment's result depend on what was decoded before it
+// (wsprd.c:481-494, 842-852); segments of a batch are decoded concurrently, so the option is honoured for
+// single-segment calls only and REFUSED -- not silently dropped -- for batches.
+int refuse_hashtable_batch(const char* where, int nseg, int* n_results) {
+    for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+    fprintf(stderr, "libwspr_mi355x: %s: usehashtable = 1 is only defined for one segment per call "
+                    "(hashtable.txt orders the calls); decode the segments one by one or clear the option\n", where);
+    return -2;
+}
+// device scratch of one call, released on every exit path
+struct TempDev {
+    void* p = nullptr;
+    explicit TempDev(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes)); }
+    ~TempDev() { if (p) (void)hipFree(p); }
+    TempDev(const TempDev&) = delete;
+    TempDev& operator=(const TempDev&) = delete;
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
 }  // namespace
 
 namespace {
@@ -96,6 +114,7 @@ size_t wspr_iq_stride(void) { return (size_t)wspr::kIqStride; }
 int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results* decodes, int max_results,
                       int* n_results, int writeback) {
+    if (options.usehashtable && nseg > 1) return refuse_hashtable_batch("wspr_decode_batch", nseg, n_results);
     try {
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
@@ -115,6 +134,7 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
 int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results) {
+    if (options.usehashtable && nseg > 1) return refuse_hashtable_batch("wspr_decode_batch_device", nseg, n_results);
     try {
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
         const float* di = static_cast<const float*>(d_idat);
@@ -187,17 +207,14 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
     try {
         Context& c = Context::get();
         c.load_host(idat, qdat, nseg, samples, seg_stride);
-        float *d_noise = nullptr, *d_sm = nullptr;
-        HIP_TRY(hipMalloc(&d_noise, (size_t)nseg * 4));
-        HIP_TRY(hipMalloc(&d_sm, (size_t)nseg * wspr::kSmooth * 4));
+        TempDev t_noise((size_t)nseg * 4), t_sm((size_t)nseg * wspr::kSmooth * 4);
+        float *d_noise = t_noise.as<float>(), *d_sm = t_sm.as<float>();
         c.run_fft_sync(nseg, samples, maxdrift, coarse != 0, nullptr, nseg, d_noise, d_sm);
         std::vector<int> npk;
         std::vector<wspr::DevCand> cd;
         c.fetch_candidates(nseg, npk, cd);
         if (noise_out) HIP_TRY(hipMemcpy(noise_out, d_noise, (size_t)nseg * 4, hipMemcpyDeviceToHost));
         if (smspec_out) HIP_TRY(hipMemcpy(smspec_out, d_sm, (size_t)nseg * wspr::kSmooth * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipFree(d_noise));
-        HIP_TRY(hipFree(d_sm));
         for (int s = 0; s < nseg; ++s) {
             npk_out[s] = npk[s];
             for (int j = 0; j < wspr::kMaxCand; ++j) {
@@ -254,6 +271,20 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
         c.sync();
         return 0;
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
+}
+
+int wspr_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int wspr_set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || device >= Context::kMaxDevices) {
+        fprintf(stderr, "libwspr_mi355x: wspr_set_device(%d): no such HIP device (%d visible)\n", device, n);
+        return -1;
+    }
+    return hipSetDevice(device) == hipSuccess ? 0 : -1;
 }
 
 int wspr_bind_thread_lane(int lane) {
@@ -320,14 +351,12 @@ int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint3
     try {
         Context& c = Context::get();
         nbytes &= ~(size_t)7;
-        void* d_raw = nullptr;
-        HIP_TRY(hipMalloc(&d_raw, nbytes + 16));
-        HIP_TRY(hipMemcpy(d_raw, iq, nbytes, hipMemcpyHostToDevice));
+        TempDev raw(nbytes + 16);
+        HIP_TRY(hipMemcpy(raw.p, iq, nbytes, hipMemcpyHostToDevice));
         float* wi = c.work_i(1);
         float* wq = c.work_q(1);
         int nout = 0;
-        const int rc = c.decimate_device(d_raw, nbytes, 1, wi, wq, normalise, &nout);
-        HIP_TRY(hipFree(d_raw));
+        const int rc = c.decimate_device(raw.p, nbytes, 1, wi, wq, normalise, &nout);
         if (rc) return rc;
         HIP_TRY(hipMemcpy(I, wi, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(Q, wq, (size_t)wspr::kMaxSamples * 4, hipMemcpyDeviceToHost));

@@ -47,6 +47,7 @@ public:
     static Context& slot(int i);    // i in [0, slots())
     static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
     static constexpr int kMaxLanes = 4;
+    static constexpr int kMaxDevices = 16;
     static int lane();              // lane of the calling thread
     static void bind_lane(int lane);
     int device();

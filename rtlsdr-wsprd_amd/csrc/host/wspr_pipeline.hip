@@ -290,11 +290,17 @@ static thread_local int t_lane = 0;
 int Context::lane() { return t_lane; }
 void Context::bind_lane(int lane) { t_lane = std::max(0, std::min(lane, kMaxLanes - 1)); }
 
+// Contexts are kept per (device, lane, slot): a host thread decodes on the HIP device that is current for it
+// (hipSetDevice / wspr_set_device), so one process can drive every GPU of a node, one thread (or more) each.
 Context& Context::slot(int i) {
     static std::mutex m;
-    static std::unique_ptr<Context> ctx[kMaxLanes][8];
+    static std::unique_ptr<Context> ctx[kMaxDevices][kMaxLanes][8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
+    if (dev < 0 || dev >= kMaxDevices) throw std::runtime_error("libwspr_mi355x: device index out of range");
     std::lock_guard<std::mutex> g(m);
-    std::unique_ptr<Context>& p = ctx[t_lane][i];
+    std::unique_ptr<Context>& p = ctx[dev][t_lane][i];
     if (!p) p.reset(new Context(slots()));
     return *p;
 }
@@ -395,6 +401,23 @@ void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevC
     HIP_OK(hipMemcpyAsync(npk.data(), d->npk.p, (size_t)nseg * 4, hipMemcpyDeviceToHost, d->stream));
     HIP_OK(hipMemcpyAsync(cand.data(), d->cand.p, (size_t)nseg * kMaxCand * sizeof(DevCand), hipMemcpyDeviceToHost, d->stream));
     HIP_OK(hipStreamSynchronize(d->stream));
+    // The reference sorts the list (built in ascending bin order) by snr = 10 log10f(peak) - 26.3 with glibc's
+    // stable merge sort (wsprd.c:616, 631).  The device ordered it with ocml's log10f, which differs from
+    // glibc's in the last bit for some arguments and could swap two nearly equal peaks -- and with them the
+    // order in which signals are subtracted.  Re-rank here with the host libm: the order (and the reported
+    // snr) then never depends on ocml.
+    d->pool->run(nseg, [&](int s) {
+        const int n = std::min(npk[s], kMaxCand);
+        if (n <= 0) return;
+        DevCand* c0 = cand.data() + (size_t)s * kMaxCand;
+        for (int j = 0; j < n; ++j) c0[j].snr = 10.0 * log10f(c0[j].peak) - (float)26.3;
+        bool sorted = true;
+        for (int j = 1; j < n && sorted; ++j)
+            sorted = c0[j - 1].snr > c0[j].snr || (c0[j - 1].snr == c0[j].snr && c0[j - 1].bin < c0[j].bin);
+        if (sorted) return;
+        std::sort(c0, c0 + n, [](const DevCand& a, const DevCand& b) { return a.bin < b.bin; });
+        std::stable_sort(c0, c0 + n, [](const DevCand& a, const DevCand& b) { return a.snr > b.snr; });
+    });
 }
 
 // ---------------------------------------------------------------- decoding ---
@@ -405,6 +428,7 @@ struct SegBook {                 // host bookkeeping of one segment across passe
     float allfreqs[100];
     char  allcalls[100][13];
     std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
+    std::vector<decoder_results> spots;   // every unique spot, in decode order (the reference's 100 at most)
 };
 
 struct WaveItem {
@@ -604,6 +628,7 @@ struct Context::DecodeRun {
     std::vector<SubJob> keep_books(std::vector<WaveItem>& wave);
     void subtract(const std::vector<SubJob>& jobs);
     void finish(const std::vector<int>& active0, int* n_results);
+    void clear_hash(const std::vector<int>& segs);
 };
 
 // Callsign hash memory across calls (wsprd.c:481-494): hashtable.txt in the working directory.
@@ -923,13 +948,15 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         snprintf(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], "%s", callsign);
         bk.allfreqs[bk.uniques] = w.fine.freq;
         bk.uniques++;
-        if (bk.uniques <= max_results) {
-            decoder_results* o = out + (size_t)s * max_results + (bk.uniques - 1);
+        {
+            bk.spots.emplace_back();
+            decoder_results* o = &bk.spots.back();
+            memset(o, 0, sizeof *o);
             const double dial = (double)opt.freq / 1e6;
             o->sync = w.fine.sync;
             // candidates[j].snr, wsprd.c:616, recomputed with the host libm from the
             // peak value so that the reported figure does not depend on ocml's log10f
-            o->snr = 10.0 * log10f(cd.peak) - (float)26.3;
+            o->snr = cd.snr;               // host libm, see fetch_candidates()
             o->dt = w.fine.shift * 1.0 / 375.0 - 2.0;
             o->freq = dial + (1500.0 + w.fine.freq) / 1e6;
             o->drift = w.fine.drift;
@@ -963,21 +990,30 @@ void Context::DecodeRun::subtract(const std::vector<SubJob>& jobs) {
     t.stop();
 }
 
-// results strongest first (wsprd.c:827; stable like glibc's merge sort); hash slots written by the
-// batch are cleared again
-void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results) {
-    for (int s : active0) {
-        SegBook& bk = book[s];
-        const int n = std::min(bk.uniques, max_results);
-        decoder_results* o = out + (size_t)s * max_results;
-        std::stable_sort(o, o + n, [](const decoder_results& a, const decoder_results& b) { return a.snr > b.snr; });
-        n_results[s] = n;
-        for (int slot : bk.dirty) {
-            if (persist) break;
+// results strongest first (wsprd.c:827; stable like glibc's merge sort) -- ALL unique spots of the segment
+// are ranked, then the strongest max_results are handed out (a caller with a short array loses the weakest
+// spots, never a strong one that happened to decode late); hash slots written by the batch are cleared again
+void Context::DecodeRun::clear_hash(const std::vector<int>& segs) {
+    if (persist) return;
+    for (int s : segs) {
+        for (int slot : book[s].dirty) {
             memset(hashtab_of(s) + (size_t)slot * kHashWidth, 0, kHashWidth);
             memset(loctab_of(s) + (size_t)slot * kLocWidth, 0, kLocWidth);
         }
+        book[s].dirty.clear();
     }
+}
+
+void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results) {
+    for (int s : active0) {
+        SegBook& bk = book[s];
+        std::stable_sort(bk.spots.begin(), bk.spots.end(),
+                         [](const decoder_results& a, const decoder_results& b) { return a.snr > b.snr; });
+        const int n = std::min((int)bk.spots.size(), max_results);
+        if (n > 0) memcpy(out + (size_t)s * max_results, bk.spots.data(), (size_t)n * sizeof(decoder_results));
+        n_results[s] = n;
+    }
+    clear_hash(active0);
     save_hash_file();
 }
 
@@ -990,6 +1026,16 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
     for (int s : active0) n_results[s] = 0;
     DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
     run.memo = memo;
+    // whatever happens below (a HIP error surfaces as an exception), the call signs this run wrote into the
+    // context's hash memory must not survive into the next batch on this lane/slot
+    struct HashGuard {
+        DecodeRun& r; const std::vector<int>& segs; bool armed = true;
+        ~HashGuard() {
+            if (!armed) return;
+            if (r.persist) memset(r.hashtab_of(0), 0, r.per_seg);
+            else r.clear_hash(segs);
+        }
+    } guard{run, active0};
     run.load_hash_file();
     std::vector<int> active = active0;
     for (int ipass = 0; ipass < opt.npasses; ++ipass) {
@@ -1009,6 +1055,7 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
         }
     }
     run.finish(active0, n_results);
+    guard.armed = false;
     return 0;
 }
 

@@ -112,11 +112,11 @@ __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 // One FFT of the run: window, 3 passes, power into the workgroup's output tile.  `raw` is the sliding
 // window of raw samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block
 // instead of moving registers needs the run loop unrolled by 4 (kBase is a compile-time constant).
-template <int kBase, int kPitch>
+template <int kBase, int kPitch, bool kBarrierBeforeWrite = false>
 __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], const Tw& twA, const Tw& twB, float w8,
                                         v2* __restrict__ X, int lane, int a, int c,
                                         const float* __restrict__ si, const float* __restrict__ sq, int t, bool more,
-                                        float* __restrict__ otile, int tl) {
+                                        float* __restrict__ otile, const int (&ocol)[8], int tl) {
     v2 x[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = raw[(kBase + r) & 7] * win[r];
@@ -146,17 +146,28 @@ __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], con
 
     pass3_last(x, w8);
 
-    // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane)
+    // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane); ocol[r] = its row offset in the output
+    // tile, or negative for the bins nobody reads (out_columns())
+    if (kBarrierBeforeWrite) __syncthreads();       // fused kernel: the previous group's tile has been consumed
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (ocol[r] >= 0) {
+            const v2 e = x[r] * x[r];
+            otile[ocol[r] + tl] = e.x + e.y;                    // 64 lanes -> 64 different bins: 2 lanes per bank
+        }
+    }
+}
+
+// tile row offset of register r's bin for this lane (fft-shifted bins 48..464 are kept), else -1
+template <int kPitch>
+__device__ __forceinline__ void out_columns(int lane, int (&ocol)[8]) {
     const int lo = (int)rev6((unsigned)lane);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
         const int bin = ((64 * rev3 + lo) + kFftSize / 2) & (kFftSize - 1);   // fft-shift
         const int col = bin - kPsBin0;
-        if (col >= 0 && col < kPsBins) {
-            const v2 e = x[r] * x[r];
-            otile[col * kPitch + tl] = e.x + e.y;            // 64 lanes -> 64 different bins: 2 lanes per bank
-        }
+        ocol[r] = (col >= 0 && col < kPsBins) ? col * kPitch : -1;
     }
 }
 
@@ -196,6 +207,8 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
         set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
         set_tw(twB, 6, twiddle[32 * c]);
         const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
+        int ocol[8];
+        out_columns<kOutPitch>(lane, ocol);
 
         v2 raw[8];
 #pragma unroll
@@ -204,13 +217,13 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
             raw[r] = v2{si[k], sq[k]};
         }
         for (int t = t_begin; t < t_end; t += 4) {
-            one_fft<0, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t, t + 1 < t_end, otile, t - t0);
+            one_fft<0, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t, t + 1 < t_end, otile, ocol, t - t0);
             if (t + 1 >= t_end) break;
-            one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 1, t + 2 < t_end, otile, t + 1 - t0);
+            one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 1, t + 2 < t_end, otile, ocol, t + 1 - t0);
             if (t + 2 >= t_end) break;
-            one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 2, t + 3 < t_end, otile, t + 2 - t0);
+            one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 2, t + 3 < t_end, otile, ocol, t + 2 - t0);
             if (t + 3 >= t_end) break;
-            one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 3, t + 4 < t_end, otile, t + 3 - t0);
+            one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t + 3, t + 4 < t_end, otile, ocol, t + 3 - t0);
         }
     }
     __syncthreads();
@@ -242,7 +255,7 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
 // the stage's HBM traffic drops from IQ + 2 x ps to IQ + ps.  A wave's four blocks are consecutive (sliding
 // sample window inside the group); between groups the window is reloaded (the rows come from the caches).
 template <int kRun>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 47 KB of LDS: three workgroups per CU
 void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                          const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
                          float* __restrict__ psavg, const float* __restrict__ window,
@@ -272,6 +285,8 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
     set_tw(twB, 6, twiddle[32 * c]);
     const float w8 = twiddle[64].x;
+    int ocol[8];
+    out_columns<kOutPitch>(lane, ocol);
 
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int kParts = kWgTimes / 4;
@@ -279,24 +294,45 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     const int b_lo = threadIdx.x, b_hi = threadIdx.x + 256;              // the bins this thread averages
     float acc_lo = 0.0f, acc_hi = 0.0f;
 
+    // the first window of a group is fetched while the previous group's tile is stored and averaged
+    v2 nxt[8];
+    {
+        const int tb = wave * kRun;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = kHop * min(tb, blocks - 1) + 64 * r + lane;
+            nxt[r] = v2{si[k], sq[k]};
+        }
+    }
     for (int t0 = 0; t0 < blocks; t0 += kWgTimes) {
         const int t_begin = t0 + wave * kRun;
         const int t_end = min(t_begin + kRun, blocks);
         if (t_begin < t_end) {
             v2 raw[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int k = kHop * t_begin + 64 * r + lane;
-                raw[r] = v2{si[k], sq[k]};
-            }
+            for (int r = 0; r < 8; ++r) raw[r] = nxt[r];
             static_assert(kRun == 4, "the group loop below is written for four blocks per wave");
-            one_fft<0, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin, t_begin + 1 < t_end, otile, t_begin - t0);
+            // the barrier that frees the tile sits inside the first FFT, just before its powers are written:
+            // a wave that is done with the previous tile starts computing at once
+            one_fft<0, kOutPitch, true>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin, t_begin + 1 < t_end, otile, ocol, t_begin - t0);
             if (t_begin + 1 < t_end)
-                one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 1, t_begin + 2 < t_end, otile, t_begin + 1 - t0);
+                one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 1, t_begin + 2 < t_end, otile, ocol, t_begin + 1 - t0);
             if (t_begin + 2 < t_end)
-                one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 2, t_begin + 3 < t_end, otile, t_begin + 2 - t0);
+                one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 2, t_begin + 3 < t_end, otile, ocol, t_begin + 2 - t0);
             if (t_begin + 3 < t_end)
-                one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 3, false, otile, t_begin + 3 - t0);
+                one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 3, false, otile, ocol, t_begin + 3 - t0);
+        } else {
+            __syncthreads();
+        }
+        {
+            const int tb = t_begin + kWgTimes;
+            if (tb < blocks) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = kHop * tb + 64 * r + lane;
+                    nxt[r] = v2{si[k], sq[k]};
+                }
+            }
         }
         __syncthreads();                                               // the group's tile is complete
         const int nt = min(kWgTimes, blocks - t0);
@@ -327,7 +363,6 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
                 if (b_hi < kPsBins) for (int j = 0; j < nt; ++j) acc_hi += m1[j];
             }
         }
-        __syncthreads();                                               // the tile may be overwritten
     }
     psavg[(size_t)seg * kPsStride + b_lo] = acc_lo;
     if (b_hi < kPsBins) psavg[(size_t)seg * kPsStride + b_hi] = acc_hi;

@@ -174,6 +174,7 @@ void pick_peaks_kernel(const float* __restrict__ psavg, const int* __restrict__ 
         cd.shift = 0;
         cd.drift = 0.0f;
         cd.sync  = 0.0f;
+        cd.bin   = j;
         cand[(size_t)seg * kMaxCand + rank] = cd;
     }
 }

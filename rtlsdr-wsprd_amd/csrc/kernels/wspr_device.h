@@ -41,6 +41,7 @@ struct DevCand {
     int   shift;    // samples
     float drift;    // Hz over the frame
     float sync;
+    int   bin;      // index of the peak in the smoothed spectrum (the reference's list order before its sort)
 };
 
 // One candidate being refined/demodulated (fine sync, soft symbols)

@@ -48,13 +48,8 @@ def gather_spots(packed, dst=0):
     Returns on dst a uint8 tensor [world, nseg, rec] (CPU), elsewhere None."""
     world, rank = dist.get_world_size(), dist.get_rank()
     t = packed.to(_dev())
-    if dist.get_backend() == "nccl":
-        # RCCL gather
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst)
-    else:
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst)
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bufs, dst=dst)                    # RCCL over xGMI under "nccl", TCP under "gloo"
     if rank != dst:
         return None
     return torch.stack(bufs).cpu()
@@ -86,10 +81,14 @@ class SpotGatherer:
             self.cnt_host = torch.empty((self.world, nseg), dtype=torch.int32, pin_memory=pin)
         else:
             self.rec_all = self.cnt_all = None
+        self._h2d_done = torch.cuda.Event() if self.nccl else None      # the staging buffers are free again
 
     def stage(self):
         """Host copy of the decoder's result arrays into the gatherer's own (pinned) staging buffers;
         afterwards the decoder may be reused while exchange() runs."""
+        # the previous exchange()'s host-to-device copies read these pinned buffers asynchronously
+        if self._h2d_done is not None:
+            self._h2d_done.synchronize()
         # plain memcpy through numpy views (a torch CPU copy would wake its intra-op thread pool)
         np.copyto(self._rec_stage_np, self._rec_src_np)
         np.copyto(self._cnt_stage_np, self._cnt_src_np)
@@ -103,6 +102,8 @@ class SpotGatherer:
         """Returns (counts [world, nseg] int32, records [world, nseg, K*record] uint8) on dst, else None."""
         self.rec_dev.copy_(self.rec_stage, non_blocking=True)
         self.cnt_dev.copy_(self.cnt_stage, non_blocking=True)
+        if self._h2d_done is not None:
+            self._h2d_done.record()
         dist.gather(self.rec_dev, self.rec_all, dst=self.dst)
         dist.gather(self.cnt_dev, self.cnt_all, dst=self.dst)
         if self.rank != self.dst:
