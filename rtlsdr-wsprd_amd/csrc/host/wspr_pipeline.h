@@ -71,6 +71,8 @@ public:
     void run_fft_sync(int nseg, int samples, int maxdrift, bool coarse, const int* d_seglist, int nactive,
                       float* noise_out, float* smspec_out);
     void fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand);
+    void fetch_candidates_async(int nseg);                 // copies queued on the stream ...
+    void finish_fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand);   // ... consumed after a wait
 
     // the decoder proper, on the working buffers
     // reload(segs): restore the original IQ of the listed segments in the working buffers (needed

@@ -156,7 +156,9 @@ struct Context::Impl {
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
         nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, streamraw, streamstate;
-    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_seglist, h_misc, h_lists;
+    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
+    int sub_flip = 0;
+    int cand_head = 16;              // candidates per segment copied to the host (adapts to the lists seen)
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
     int jitter_ladder[kMaxLags];
@@ -168,6 +170,19 @@ struct Context::Impl {
     bool blocking = false;
     hipEvent_t ev_sync = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // spans timed without a host wait: event pairs recorded around the launches, read back after a later
+    // synchronisation of the same (in-order) stream has passed them
+    static constexpr int kDeferred = 8;
+    hipEvent_t ev_def[kDeferred][2] = {};
+    double* def_acc[kDeferred] = {};
+    int n_def = 0;
+    void resolve_deferred() {
+        for (int i = 0; i < n_def; ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev_def[i][0], ev_def[i][1]) == hipSuccess) *def_acc[i] += ms;
+        }
+        n_def = 0;
+    }
 };
 
 // CPUs this process may actually use: hardware threads capped by the cgroup CPU quota
@@ -219,6 +234,7 @@ Context::Context(int nslots) : d(new Impl) {
     HIP_OK(hipEventCreateWithFlags(&d->ev[0], evflags));
     HIP_OK(hipEventCreateWithFlags(&d->ev[1], evflags));
     HIP_OK(hipEventCreateWithFlags(&d->ev_sync, evflags | hipEventDisableTiming));
+    for (auto& pr : d->ev_def) { HIP_OK(hipEventCreate(&pr[0])); HIP_OK(hipEventCreate(&pr[1])); }
 
     // constant tables, computed with the host libm exactly as the reference does
     std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
@@ -353,6 +369,7 @@ void Context::sync() {
     } else {
         HIP_OK(hipStreamSynchronize(d->stream));
     }
+    d->resolve_deferred();
 }
 
 float* Context::ps_buffer(int nseg) {
@@ -395,18 +412,43 @@ void Context::run_fft_sync(int nseg, int samples, int maxdrift, bool coarse, con
     if (coarse) launch_coarse_sync(ps, d_seglist, nactive, blocks, cand, npk, maxdrift, d->tab, d->stream);
 }
 
-void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
+// Candidate lists to the host.  A segment rarely holds more than a dozen candidates of its 200 slots, so only
+// the head of every list is copied (2-D copy into pinned memory, `cand_head` entries per segment, adapted to
+// the lists seen so far); a batch with a longer list is fetched again in full.
+void Context::fetch_candidates_async(int nseg) {
+    Impl& c = *d;
+    const int head = c.cand_head;
+    int* h_npk = static_cast<int*>(c.h_npk.need((size_t)nseg * 4));
+    DevCand* h_cand = static_cast<DevCand*>(c.h_cand.need((size_t)nseg * kMaxCand * sizeof(DevCand)));
+    HIP_OK(hipMemcpyAsync(h_npk, c.npk.p, (size_t)nseg * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpy2DAsync(h_cand, (size_t)head * sizeof(DevCand), c.cand.p, (size_t)kMaxCand * sizeof(DevCand),
+                            (size_t)head * sizeof(DevCand), nseg, hipMemcpyDeviceToHost, c.stream));
+}
+
+void Context::finish_fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
+    Impl& c = *d;
     npk.resize(nseg);
     cand.resize((size_t)nseg * kMaxCand);
-    HIP_OK(hipMemcpyAsync(npk.data(), d->npk.p, (size_t)nseg * 4, hipMemcpyDeviceToHost, d->stream));
-    HIP_OK(hipMemcpyAsync(cand.data(), d->cand.p, (size_t)nseg * kMaxCand * sizeof(DevCand), hipMemcpyDeviceToHost, d->stream));
-    HIP_OK(hipStreamSynchronize(d->stream));
+    const int* h_npk = c.h_npk.as<int>();
+    const DevCand* h_cand = c.h_cand.as<DevCand>();
+    int longest = 0;
+    for (int s = 0; s < nseg; ++s) { npk[s] = h_npk[s]; longest = std::max(longest, std::min(h_npk[s], kMaxCand)); }
+    const int head = c.cand_head;
+    if (longest > head) {                                   // rare: fetch the full lists
+        HIP_OK(hipMemcpyAsync(c.h_cand.p, c.cand.p, (size_t)nseg * kMaxCand * sizeof(DevCand), hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipStreamSynchronize(c.stream));
+        memcpy(cand.data(), h_cand, (size_t)nseg * kMaxCand * sizeof(DevCand));
+    } else {
+        for (int s = 0; s < nseg; ++s)
+            memcpy(cand.data() + (size_t)s * kMaxCand, h_cand + (size_t)s * head, (size_t)std::min(npk[s], head) * sizeof(DevCand));
+    }
+    c.cand_head = std::min(kMaxCand, std::max(16, (longest + 15) / 8 * 8));
     // The reference sorts the list (built in ascending bin order) by snr = 10 log10f(peak) - 26.3 with glibc's
     // stable merge sort (wsprd.c:616, 631).  The device ordered it with ocml's log10f, which differs from
     // glibc's in the last bit for some arguments and could swap two nearly equal peaks -- and with them the
     // order in which signals are subtracted.  Re-rank here with the host libm: the order (and the reported
     // snr) then never depends on ocml.
-    d->pool->run(nseg, [&](int s) {
+    c.pool->run(nseg, [&](int s) {
         const int n = std::min(npk[s], kMaxCand);
         if (n <= 0) return;
         DevCand* c0 = cand.data() + (size_t)s * kMaxCand;
@@ -418,6 +460,12 @@ void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevC
         std::sort(c0, c0 + n, [](const DevCand& a, const DevCand& b) { return a.bin < b.bin; });
         std::stable_sort(c0, c0 + n, [](const DevCand& a, const DevCand& b) { return a.snr > b.snr; });
     });
+}
+
+void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
+    fetch_candidates_async(nseg);
+    HIP_OK(hipStreamSynchronize(d->stream));
+    finish_fetch_candidates(nseg, npk, cand);
 }
 
 // ---------------------------------------------------------------- decoding ---
@@ -458,6 +506,7 @@ struct Timer {
         *acc += ms;
     }
 };
+
 
 }  // namespace
 
@@ -678,9 +727,11 @@ void Context::DecodeRun::start_pass(int pass, const std::vector<int>& active) {
     {
         Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[0]);
         ctx.run_fft_sync(nseg, samples, maxdrift, true, d_seglist, nact, nullptr, nullptr);
-        t.stop();
+        ctx.fetch_candidates_async(nseg);
+        t.stop();                                   // the one host wait of the pass start
+        c.resolve_deferred();
     }
-    ctx.fetch_candidates(nseg, npk, cand);
+    ctx.finish_fetch_candidates(nseg, npk, cand);
     lockstep = opt.subtraction && ipass == 0;
     stopped.assign(nseg, 0);
     next_cand.assign(nseg, 0);
@@ -743,7 +794,16 @@ std::vector<WaveItem> Context::DecodeRun::build_wave(const std::vector<int>& act
 // GPU: fine sync (mode 0, mode 1) and first soft-symbol attempt; host: first rung of the jitter ladder
 void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
     const int nw = (int)wave.size();
-    h_items = static_cast<FineState*>(c.h_items.need((size_t)nw * sizeof(FineState)));
+    // One block up, one block down per wave (a small copy costs a blit kernel on the stream and ~10 us of
+    // host time each): up = [items | launch lists], down = [items | rung-0 sync | rung-0 rms | rung-0 symbols].
+    const size_t up_bytes = (size_t)nw * sizeof(FineState) + (size_t)nw * 2 * 4;
+    const size_t o_sync = (size_t)nw * sizeof(FineState), o_rms = o_sync + (size_t)nw * 4, o_sym = o_rms + (size_t)nw * 4;
+    const size_t down_bytes = o_sym + (size_t)nw * kNSymD;
+    char* h_up = static_cast<char*>(c.h_items.need(up_bytes));
+    char* h_down = static_cast<char*>(c.h_sym.need(std::max(down_bytes, (size_t)nw * kMaxLags * (kNSymD + 8))));
+    char* d_blk = static_cast<char*>(c.items.need(std::max(up_bytes, down_bytes)));
+    h_items = reinterpret_cast<FineState*>(h_up);
+    h_lists = reinterpret_cast<int*>(h_up + (size_t)nw * sizeof(FineState));
     for (int i = 0; i < nw; ++i) {
         const DevCand& cd = cand[(size_t)wave[i].seg * kMaxCand + wave[i].cand];
         FineState f{};
@@ -751,22 +811,22 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
         f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
         h_items[i] = f;
     }
-    d_items = static_cast<FineState*>(c.items.need((size_t)nw * sizeof(FineState)));
-    h_lists = static_cast<int*>(c.h_lists.need((size_t)nw * 2 * 4));
     n_shared = n_own = 0;
     const size_t ntabs = plan_tables(h_items, nw, h_lists, &n_shared, &n_own);
+    d_items = reinterpret_cast<FineState*>(d_blk);
+    // the launch lists are read by every kernel of the wave while the rung-0 outputs land behind the items:
+    // keep the lists in their own buffer
     d_lists = static_cast<int*>(c.lists.need((size_t)nw * 2 * 4));
     d_tabs = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)nw * 5) * 2048 * 4));
     d_pw = static_cast<float*>(c.pw.need((size_t)nw * kMaxLags * kNSymD * 16));
     const int nh_max = std::max(nlag0, kMaxLags);
     d_sync = static_cast<float*>(c.syncbuf.need((size_t)nw * nh_max * 4));
-    d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
-    d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
+    c.symbuf.need((size_t)nw * kMaxLags * (kNSymD + 8));      // sized for the 43-lag block of remaining_rungs()
+    float* d_sync0 = reinterpret_cast<float*>(d_blk + o_sync);
+    float* d_rms0 = reinterpret_cast<float*>(d_blk + o_rms);
+    unsigned char* d_sym0 = reinterpret_cast<unsigned char*>(d_blk + o_sym);
     const float* wi = c.iqI.as<float>();
     const float* wq = c.iqQ.as<float>();
-    h_sync = static_cast<float*>(c.h_sync.need((size_t)nw * kMaxLags * 4));
-    h_rms = static_cast<float*>(c.h_rms.need((size_t)nw * kMaxLags * 4));
-    h_sym = static_cast<unsigned char*>(c.h_sym.need((size_t)nw * kMaxLags * kNSymD));
     {
         Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[3]);
         upload(d_items, h_items, (size_t)nw * sizeof(FineState), c.stream);
@@ -780,15 +840,18 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
             float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
             float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
             launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, lagstep,
-                                            minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync, d_sym,
-                                            d_rms, c.tab, c.stream);
+                                            minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync0, d_sym0,
+                                            d_rms0, c.tab, c.stream);
         }
-        HIP_OK(hipMemcpyAsync(h_items, d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)nw * 4, hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)nw * kNSymD, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(h_down, d_blk, down_bytes, hipMemcpyDeviceToHost, c.stream));
         t.stop();
+        c.resolve_deferred();
     }
+    // host views of the block that came down (h_items is re-pointed: the uploaded copy is no longer needed)
+    h_items = reinterpret_cast<FineState*>(h_down);
+    h_sync = reinterpret_cast<float*>(h_down + o_sync);
+    h_rms = reinterpret_cast<float*>(h_down + o_rms);
+    h_sym = reinterpret_cast<unsigned char*>(h_down + o_sym);
 
     // ---- host: first rung of the jitter ladder ----------------------------
     const auto t_f0 = std::chrono::steady_clock::now();
@@ -838,12 +901,21 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             upload(d_items, h2, (size_t)na * sizeof(FineState), c.stream);
             upload(d_lists, h_lists, (size_t)na * 2 * 4, c.stream);
             launch_phasor_tables(d_items, na, 2, d_tabs, c.stream);
+            // the 43-lag outputs in one block [sync | rms | symbols] -> one copy down
+            const size_t o_rms = (size_t)na * kMaxLags * 4, o_sym = 2 * o_rms, blk = o_sym + (size_t)na * kMaxLags * kNSymD;
+            char* d_blk = static_cast<char*>(c.symbuf.need(blk));
+            char* h_blk = static_cast<char*>(c.h_sym.need(blk));
+            d_sync = reinterpret_cast<float*>(d_blk);
+            d_rms = reinterpret_cast<float*>(d_blk + o_rms);
+            d_sym = reinterpret_cast<unsigned char*>(d_blk + o_sym);
             launch_demod_tiled(wi, wq, samples, d_items, na, d_lists, n_shared, d_lists + na, n_own, 2, kMaxLags, 3,
                                minsync1, d_tabs, d_pw, d_sync, d_sym, d_rms, c.tab, c.stream);
-            HIP_OK(hipMemcpyAsync(h_sync, d_sync, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_OK(hipMemcpyAsync(h_rms, d_rms, (size_t)na * kMaxLags * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_OK(hipMemcpyAsync(h_sym, d_sym, (size_t)na * kMaxLags * kNSymD, hipMemcpyDeviceToHost, c.stream));
+            HIP_OK(hipMemcpyAsync(h_blk, d_blk, blk, hipMemcpyDeviceToHost, c.stream));
             t.stop();
+            c.resolve_deferred();
+            h_sync = reinterpret_cast<float*>(h_blk);
+            h_rms = reinterpret_cast<float*>(h_blk + o_rms);
+            h_sym = reinterpret_cast<unsigned char*>(h_blk + o_sym);
         }
         const auto t_f1 = std::chrono::steady_clock::now();
         // every (candidate, rung) Fano attempt is independent; the ladder keeps the
@@ -980,14 +1052,26 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
 void Context::DecodeRun::subtract(const std::vector<SubJob>& jobs) {
     if (jobs.empty()) return;
     const int nj = (int)jobs.size();
-    SubJob* hj = static_cast<SubJob*>(c.h_jobs.need((size_t)nj * sizeof(SubJob)));
+    // two pinned staging buffers in turn: the upload is asynchronous, and the copy that read the other one
+    // has completed by the time it is reused (a blocking wait on this stream lies between two subtractions)
+    PinBuf& stage = (c.sub_flip ^= 1) ? c.h_jobs : c.h_jobs2;
+    SubJob* hj = static_cast<SubJob*>(stage.need((size_t)nj * sizeof(SubJob)));
     memcpy(hj, jobs.data(), (size_t)nj * sizeof(SubJob));
     SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nj * sizeof(SubJob)));
     float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nj) * 4));
-    Timer t(c.ev[0], c.ev[1], c.stream, &c.t_ms[4]);
+    // no host wait here: the next wave's kernels queue behind the subtraction on the same stream, and nothing
+    // the host does next depends on it.  The span is timed with a deferred event pair (or not at all if eight
+    // are already pending).
+    const int slot_ev = c.n_def < Impl::kDeferred ? c.n_def : -1;
+    if (slot_ev >= 0) HIP_OK(hipEventRecord(c.ev_def[slot_ev][0], c.stream));
     upload(dj, hj, (size_t)nj * sizeof(SubJob), c.stream);
     launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nj, scratch, c.tab, c.stream);
-    t.stop();
+    if (slot_ev >= 0) {
+        HIP_OK(hipEventRecord(c.ev_def[slot_ev][1], c.stream));
+        c.def_acc[slot_ev] = &c.t_ms[4];
+        c.n_def = slot_ev + 1;
+    }
+    HIP_OK(hipGetLastError());
 }
 
 // results strongest first (wsprd.c:827; stable like glibc's merge sort) -- ALL unique spots of the segment
