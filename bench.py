@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
     ap.add_argument("--fano-fast", type=int, default=None,
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
-                         "default 200; 10000 = no split)")
+                         "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight (default 2 when the rank has >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
@@ -259,7 +259,9 @@ def main():
             if nseg >= 1024 and "WSPR_FANO_FAST" not in os.environ:
                 # crowded band, thousands of Fano time-outs per step: short host budget + device tail (K6w);
                 # results are those of the full budget by construction
-                fast = args.fano_fast if args.fano_fast else 200
+                # the fewer CPUs a rank has, the earlier an attempt is handed to the device tail (measured with
+                # 2 host threads: 5.2k / 6.2k / 6.7k segments/s at 200 / 60 / 25 cycles per bit)
+                fast = args.fano_fast if args.fano_fast else (200 if cpus_here >= 8 else (60 if cpus_here >= 4 else 25))
                 fast_old = L.wspr_set_fano_fast_budget(C.c_uint(fast))
                 workload += "; host Fano budget %d cycles/bit, the rest on the device tail (exact)" % fast
         else:

@@ -17,14 +17,15 @@
 // Integer work, LDS-latency bound; 21 KB of LDS per wave -> 7 waves per CU.
 #include "wspr_device.h"
 #include "fano_wave.h"
+#include <cstdlib>
 
 namespace wspr {
 namespace {
 
 using namespace fano_wave;
 
-constexpr int kCap = 1024;            // pending visits per wave (a serial walk needs < 100; 64-wide steps ~1700 at
-                                      // most in tests -- the step narrows when the stack fills, see below)
+// pending visits per wave: template parameter kCap (a serial walk needs < 100, 64-wide steps ~1700 at most in
+// tests -- the step narrows when the stack fills, see below); 20 bytes of LDS each
 
 // inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, gfx9 idiom)
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
@@ -43,6 +44,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // popco
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+template <int kCap>
 __global__ __launch_bounds__(64)
 void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __restrict__ offsets, int n,
                       const short* __restrict__ metric0, unsigned maxcycles,
@@ -167,7 +169,11 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
             p_led[w] = keep_self ? 0u : tail_led;
         }
         size = base + total;
-        __syncthreads();
+        // one wave: its LDS operations complete in order, so the next step's reads see these writes; only the
+        // compiler has to be kept from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (lane == 0) {
         ret[v] = rc;
@@ -187,8 +193,16 @@ void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, c
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
                       unsigned char* data, unsigned* steps, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(fano_wave_kernel, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
-                       cycles, metric, maxnp, data, steps);
+    static const int cap = [] { const char* e = getenv("WSPR_FANO_WAVE_CAP"); return e ? atoi(e) : 1024; }();
+    if (cap == 512)
+        hipLaunchKernelGGL(fano_wave_kernel<512>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
+                           cycles, metric, maxnp, data, steps);
+    else if (cap == 768)
+        hipLaunchKernelGGL(fano_wave_kernel<768>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
+                           cycles, metric, maxnp, data, steps);
+    else
+        hipLaunchKernelGGL(fano_wave_kernel<1024>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
+                           cycles, metric, maxnp, data, steps);
 }
 
 }  // namespace wspr

@@ -23,12 +23,18 @@ def _segments():
     return [synth.make_segment(500 + s, symf, snr_db=-14.0) for s in range(NSEG)]
 
 
-def _decode_shard(lo, hi, segs, opt):
+def _decode_shard(lo, hi, segs, opt, product=False):
     import oracle_lib as ol
     import rtlsdr_wsprd_amd as w
     n = hi - lo
     out = (w.decoder_results * (n * K))()
     cnt = (C.c_int * n)()
+    if product:          # the HIP library itself (GPU box): one batch call for the rank's shard
+        I = np.stack([segs[s][0] for s in range(lo, hi)]); Q = np.stack([segs[s][1] for s in range(lo, hi)])
+        rc = w.lib().wspr_decode_batch(I.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), n, 45000, 45000, opt,
+                                       C.addressof(out), K, C.addressof(cnt), 0)
+        assert rc == 0
+        return out, cnt, n
     o = ol.Options.from_buffer_copy(bytes(opt))
     for i, s in enumerate(range(lo, hi)):
         spots, _, _ = ol.decode(segs[s][0], segs[s][1], 45000, o)
@@ -38,7 +44,7 @@ def _decode_shard(lo, hi, segs, opt):
     return out, cnt, n
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, product=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,7 +55,7 @@ def _worker(rank, world, port, q):
     opt = wd.broadcast_options(opt, src=0)
     assert opt.npasses == 2 and opt.subtraction == 1 and opt.freq == 144489000
     lo, hi = wd.shard_range(NSEG, rank, world)
-    out, cnt, n = _decode_shard(lo, hi, segs, opt)
+    out, cnt, n = _decode_shard(lo, hi, segs, opt, product)
     g = wd.gather_spots(wd.pack_spots(out, cnt, n, K, 80), dst=0)
     g2 = wd.SpotGatherer(out, cnt, n, K, 80, dst=0).gather()        # the preallocated path bench.py uses
     if rank == 0:
@@ -62,7 +68,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_world2_product_shards_equal_single_process_oracle():
+    """The same two-rank run on the GPU box, every rank decoding its shard THROUGH THE PRODUCT (both ranks
+    share the one GPU; the collectives stay on gloo): the gathered spots equal the single-process oracle's."""
+    _run_world2(product=True)
+
+
 def test_world2_gather_equals_single_process():
+    _run_world2(product=False)
+
+
+def _run_world2(product):
     sys.path.insert(0, ROOT)
     import rtlsdr_wsprd_amd as w
     from rtlsdr_wsprd_amd import dist as wd
@@ -70,7 +87,7 @@ def test_world2_gather_equals_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port + (7 if product else 0), q, product)) for r in range(2)]
     for p in procs:
         p.start()
     counts, msgs = q.get(timeout=300)
