@@ -44,13 +44,21 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // popco
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int kCap>
+// kGlobal: the pending-visit store lives in a per-wave slice of device memory (L2-resident: only the top of
+// the stack is touched) instead of LDS.  A step then costs two memory round trips instead of two LDS ones,
+// but a wave needs 1.3 KB of LDS instead of 21 KB, so 32 waves per CU hide that latency (7 with the LDS
+// store) and the kernel no longer starves co-running kernels of LDS.
+template <int kCap, bool kGlobal>
 __global__ __launch_bounds__(64)
 void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __restrict__ offsets, int n,
                       const short* __restrict__ metric0, unsigned maxcycles,
                       int* __restrict__ ret, unsigned* __restrict__ cycles, unsigned* __restrict__ metric,
-                      unsigned* __restrict__ maxnp, unsigned char* __restrict__ data, unsigned* __restrict__ steps_out) {
-    __shared__ uint32_t p_st[kCap], p_dlo[kCap], p_meta[kCap], p_gt[kCap], p_led[kCap];
+                      unsigned* __restrict__ maxnp, unsigned char* __restrict__ data, unsigned* __restrict__ steps_out,
+                      uint32_t* __restrict__ gpool) {
+    __shared__ uint32_t lpool[kGlobal ? 1 : 5 * kCap];
+    uint32_t* __restrict__ gp = kGlobal ? gpool + (size_t)blockIdx.x * 5 * kCap : nullptr;
+    auto ld = [&](int arr, int i) -> uint32_t { if constexpr (kGlobal) return gp[arr * kCap + i]; else return lpool[arr * kCap + i]; };
+    auto st_ = [&](int arr, int i, uint32_t v) { if constexpr (kGlobal) gp[arr * kCap + i] = v; else lpool[arr * kCap + i] = v; };
     __shared__ uint2 bm[kBits];
     __shared__ unsigned char symd[kNSymD];
     __shared__ short mt[256];
@@ -80,9 +88,10 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
                            (uint32_t)(uint16_t)(short)(a1 + b0) | ((uint32_t)(uint16_t)(short)(a1 + b1) << 16));
     }
     if (lane == 0) {                                        // the root, visited at t = 0, -60, -120, ...
-        p_st[0] = 0u; p_dlo[0] = 0u; p_meta[0] = pack_meta(0u, 0, true); p_gt[0] = pack_gt(0, 0); p_led[0] = 0u;
+        st_(0, 0, 0u); st_(1, 0, 0u); st_(2, 0, pack_meta(0u, 0, true)); st_(3, 0, pack_gt(0, 0)); st_(4, 0, 0u);
     }
     __syncthreads();
+    if constexpr (kGlobal) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
     const unsigned budget = maxcycles * (unsigned)kBits;
     int size = 1;                    // wave-uniform
@@ -104,7 +113,7 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         ++steps;
         const bool active = lane < take;
         const int idx = size - 1 - (active ? lane : 0);
-        Visit x{p_st[idx], p_dlo[idx], p_meta[idx], p_gt[idx], p_led[idx]};
+        Visit x{ld(0, idx), ld(1, idx), ld(2, idx), ld(3, idx), ld(4, idx)};
         const int pos = v_pos(x);
         const bool is_done_visit = active && pos == kPosDone;
         if (__builtin_amdgcn_readfirstlane((int)is_done_visit)) {                // earliest pending visit completes the frame
@@ -154,26 +163,33 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         const uint32_t tail_led = x.led + gain;
         if (has0) {
             const int w = top - before;
-            p_st[w] = e.kid0.st; p_dlo[w] = e.kid0.dlo; p_meta[w] = e.kid0.meta; p_gt[w] = e.kid0.gt;
-            p_led[w] = e.look1 + ((!has1 && !again) ? tail_led : 0u);
+            st_(0, w, e.kid0.st); st_(1, w, e.kid0.dlo); st_(2, w, e.kid0.meta); st_(3, w, e.kid0.gt);
+            st_(4, w, e.look1 + ((!has1 && !again) ? tail_led : 0u));
         }
         if (has1) {
             const int w = top - before - (int)has0;
-            p_st[w] = e.kid1.st; p_dlo[w] = e.kid1.dlo; p_meta[w] = e.kid1.meta; p_gt[w] = e.kid1.gt;
-            p_led[w] = !again ? tail_led : 0u;
+            st_(0, w, e.kid1.st); st_(1, w, e.kid1.dlo); st_(2, w, e.kid1.meta); st_(3, w, e.kid1.gt);
+            st_(4, w, !again ? tail_led : 0u);
         }
         if (again) {
             const int w = top - before - (int)has0 - (int)has1;
             const Visit s = is_done_visit ? x : e.self;
-            p_st[w] = s.st; p_dlo[w] = s.dlo; p_meta[w] = s.meta; p_gt[w] = s.gt;
-            p_led[w] = keep_self ? 0u : tail_led;
+            st_(0, w, s.st); st_(1, w, s.dlo); st_(2, w, s.meta); st_(3, w, s.gt);
+            st_(4, w, keep_self ? 0u : tail_led);
         }
         size = base + total;
-        // one wave: its LDS operations complete in order, so the next step's reads see these writes; only the
-        // compiler has to be kept from moving them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (kGlobal) {
+            // the stores must have reached the cache the next step's loads read from (other lanes of this
+            // wave read them): workgroup-scope release/acquire = wait for the stores, nothing is flushed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            // one wave: its LDS operations complete in order, so the next step's reads see these writes; only
+            // the compiler has to be kept from moving them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
     if (lane == 0) {
         ret[v] = rc;
@@ -189,20 +205,23 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
 
 }  // namespace
 
+size_t fano_wave_scratch_words(int n) {                     // device scratch for the global-store form
+    return (size_t)n * 5 * 4096;
+}
+
 void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, const short* metric0,
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
-                      unsigned char* data, unsigned* steps, hipStream_t st) {
+                      unsigned char* data, unsigned* steps, uint32_t* scratch, hipStream_t st) {
     if (n <= 0) return;
-    static const int cap = [] { const char* e = getenv("WSPR_FANO_WAVE_CAP"); return e ? atoi(e) : 1024; }();
-    if (cap == 512)
-        hipLaunchKernelGGL(fano_wave_kernel<512>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
-                           cycles, metric, maxnp, data, steps);
-    else if (cap == 768)
-        hipLaunchKernelGGL(fano_wave_kernel<768>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
-                           cycles, metric, maxnp, data, steps);
+    // WSPR_FANO_WAVE_STORE=lds: the 1024-visit store in LDS (7 waves per CU); default: 4096 visits per wave in
+    // device memory (scratch = fano_wave_scratch_words(n) words)
+    static const bool lds = [] { const char* e = getenv("WSPR_FANO_WAVE_STORE"); return e && e[0] == 'l'; }();
+    if (lds || !scratch)
+        hipLaunchKernelGGL((fano_wave_kernel<1024, false>), dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
+                           ret, cycles, metric, maxnp, data, steps, (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL(fano_wave_kernel<1024>, dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles, ret,
-                           cycles, metric, maxnp, data, steps);
+        hipLaunchKernelGGL((fano_wave_kernel<4096, true>), dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
+                           ret, cycles, metric, maxnp, data, steps, scratch);
 }
 
 }  // namespace wspr

@@ -134,9 +134,12 @@ void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, c
 // Device Fano search, one wavefront per vector, 64 tree visits per step (k6_fano_wave.hip): exact return
 // code, cycle count and decoded bytes; metric/maxnp only for decoded frames.  ret -2 = the wave's
 // pending-visit store overflowed (the caller decodes that vector some other way).  steps may be null.
+// scratch: fano_wave_scratch_words(n) words of device memory (the waves' pending-visit stores), or null for the
+// LDS-store form.
+size_t fano_wave_scratch_words(int n);
 void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, const short* metric0,
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
-                      unsigned char* data, unsigned* steps, hipStream_t st);
+                      unsigned char* data, unsigned* steps, uint32_t* scratch, hipStream_t st);
 void launch_normalise(float* dI, float* dQ, const int* n_valid, int nseg, int n_total, hipStream_t st);
 // resident input rows -> working rows (zero tail); false if the input is not 16-byte friendly
 bool launch_load_rows(const float* sI, const float* sQ, size_t stride, int samples, int nseg, float* dI, float* dQ,
