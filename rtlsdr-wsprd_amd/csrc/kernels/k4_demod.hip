@@ -416,28 +416,33 @@ void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restri
     }
 }
 
-// Workgroup = (candidate, frequency hypothesis), lane = symbol: 162 of 192 lanes run one serial
-// 256-sample tone correlation each.  The hypothesis' phasor table (8 KB) sits in LDS and is read
-// as a broadcast; the samples stream through LDS in chunks of 32 per symbol (coalesced 128-byte row
-// segments from HBM/L2, transposed so that lane = symbol reads conflict-free), the next chunk in
-// flight in registers while the current one is consumed.
-constexpr int kFsThreads = 192;
+// Workgroup = candidate, thread = (frequency hypothesis, symbol): 810 of 832 threads run one serial
+// 256-sample tone correlation each.  The five hypotheses share the samples (same lag), so the 162 x 32 chunk
+// is staged ONCE per workgroup (coalesced 128-byte row segments from HBM/L2, transposed so that thread =
+// symbol reads conflict-free) and serves all five; their phasor tables (5 x 8 KB) sit in LDS and a wave reads
+// them as a broadcast (a wave holds one hypothesis, two at a boundary).  The next chunk is in flight in
+// registers while the current one is consumed.  (Round 1 ran one workgroup per hypothesis: five times the
+// staging instructions and barriers for the same arithmetic -- 0.20 of the packed-pipe bound.)
+constexpr int kFsThreads = 832;                                   // 13 waves: 5 x 162 = 810 working threads
 constexpr int kFsChunk = 32;
-constexpr int kFsPerThread = kNSymD * kFsChunk / kFsThreads;      // 27 samples staged per thread and chunk
-static_assert(kNSymD * kFsChunk % kFsThreads == 0, "chunk must split evenly over the workgroup");
+constexpr int kFsPerThread = (kNSymD * kFsChunk + kFsThreads - 1) / kFsThreads;      // 7 samples staged per thread and chunk
 
 __global__ __launch_bounds__(kFsThreads)
 void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                       const FineState* __restrict__ items, const int* __restrict__ item_list,
                       const float* __restrict__ tabs, float4* __restrict__ pw_out) {
-    __shared__ float4 tab[2 * kSps];                                 // (c0..c3), (s0..s3) per sample
-    __shared__ float2 tile[kNSymD][kFsChunk + 1];
-    const int slot = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char fs_smem[];
+    float4* tab = reinterpret_cast<float4*>(fs_smem);                                   // [5][2 * 256]: (c0..c3), (s0..s3)
+    float2 (*tile)[kFsChunk + 1] = reinterpret_cast<float2 (*)[kFsChunk + 1]>(fs_smem + kNFreq * 2 * kSps * sizeof(float4));
+    const int slot = blockIdx.x, tid = threadIdx.x;
     const FineState st = items[item_list[slot]];
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps);
-    for (int e = tid; e < 2 * kSps; e += kFsThreads) tab[e] = gt[e];
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * (2 * kSps);
+    for (int e = tid; e < kNFreq * 2 * kSps; e += kFsThreads) tab[e] = gt[e];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int f = tid / kNSymD, sym = tid - f * kNSymD;
+    const bool working = f < kNFreq;
+    const float4* __restrict__ tb = tab + (working ? f : 0) * (2 * kSps);
 
     float2 nxt[kFsPerThread];
     auto fetch = [&](int c) {
@@ -445,7 +450,7 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
         for (int u = 0; u < kFsPerThread; ++u) {
             const int e = u * kFsThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
             const int k = st.shift + kSps * row + kFsChunk * c + col;
-            const bool ok = (k > 0) && (k < np);
+            const bool ok = (e < kNSymD * kFsChunk) && (k > 0) && (k < np);
             nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
         }
     };
@@ -457,19 +462,19 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
 #pragma unroll
         for (int u = 0; u < kFsPerThread; ++u) {
             const int e = u * kFsThreads + tid;
-            tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
+            if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
         }
         __syncthreads();
         if (c + 1 < kSps / kFsChunk) fetch(c + 1);
-        if (tid < kNSymD) {
+        if (working) {
 #pragma unroll 8
             for (int jj = 0; jj < kFsChunk; ++jj) {
                 const int j = kFsChunk * c + jj;
-                acc.step(tile[tid][jj], tab[2 * j], tab[2 * j + 1]);
+                acc.step(tile[sym][jj], tb[2 * j], tb[2 * j + 1]);
             }
         }
     }
-    if (tid < kNSymD) pw_out[((size_t)slot * kNFreq + f) * kNSymD + tid] = acc.amplitudes();
+    if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
 }
 
 // one wave per candidate: lanes 0..4 fold one frequency hypothesis each (162 symbols in
@@ -610,7 +615,14 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                                      float* rms_out, const DeviceTables& t, hipStream_t st) {
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-        hipLaunchKernelGGL(freq_tile_kernel, dim3(kNFreq, n_shared), dim3(kFsThreads), 0, st, dI, dQ,
+        const size_t fs_lds = kNFreq * 2 * kSps * sizeof(float4) + (size_t)kNSymD * (kFsChunk + 1) * sizeof(float2);   // 83 KB
+        static const bool once = [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&freq_tile_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds);
+            return true;
+        }();
+        (void)once;
+        hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
                            samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
                            reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
