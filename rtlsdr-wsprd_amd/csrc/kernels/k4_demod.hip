@@ -13,6 +13,7 @@
 // Bound: fp32 VALU (AI > 100 flop/B); no MFMA (separately rounded mul/add chains).
 #include "wspr_device.h"
 #include "glibc_sincosf.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -242,7 +243,8 @@ template <int STEP, bool SHARED>
 __global__ __launch_bounds__(448)
 void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
-                       int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+                       int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out,
+                       int scalar_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int item = item_list[blockIdx.y];
     const FineState st = items[item];
@@ -260,16 +262,20 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int kbase = lag0 + kSps * i0;
     const int nthr = blockDim.x;
+    // the candidate's one table (built by phasor_table_kernel): every lane of the workgroup reads the same
+    // entry at every step, so it is read through the scalar cache straight into SGPR operands of the packed
+    // multiplies (WSPR_K4_TABLE=lds restores the LDS copy: two 16-byte LDS reads per lane and step)
+    const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
+                                      (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
     if constexpr (SHARED) {
-        // the candidate's one table (built by phasor_table_kernel); loads in batches of 4 so that their
-        // latencies overlap
-        const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)st.pad * 512;
-        for (int e0 = tid; e0 < 512; e0 += 4 * nthr) {
-            float4 v[4];
+        if (!scalar_table) {
+            for (int e0 = tid; e0 < 512; e0 += 4 * nthr) {
+                float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) v[u] = gt[e]; }
+                for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) v[u] = gtab[e]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) tab[e] = v[u]; }
+                for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) tab[e] = v[u]; }
+            }
         }
     } else {
         // a drifting candidate has one table per symbol (162 x 8 KB): its 6 x 4 phasor recurrences are run
@@ -319,17 +325,33 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     if constexpr (STEP == 8 || STEP == 16) {
         // e = STEP*m + 256*il + j with STEP | 256: row = j % STEP, column = m + (256/STEP)*il + j/STEP
         const float2* __restrict__ col = tile + m + (kSps / STEP) * il;
-        for (int j0 = 0; j0 < kSps; j0 += STEP) {
-            const float2* __restrict__ t0 = col + j0 / STEP;
+        if (SHARED && scalar_table) {
+            for (int j0 = 0; j0 < kSps; j0 += STEP) {
+                const float2* __restrict__ t0 = col + j0 / STEP;
 #pragma unroll
-            for (int u = 0; u < STEP; ++u) acc.step(t0[u * pitch], tb[2 * (j0 + u)], tb[2 * (j0 + u) + 1]);
+                for (int u = 0; u < STEP; ++u) acc.step(t0[u * pitch], gtab[2 * (j0 + u)], gtab[2 * (j0 + u) + 1]);
+            }
+        } else {
+            for (int j0 = 0; j0 < kSps; j0 += STEP) {
+                const float2* __restrict__ t0 = col + j0 / STEP;
+#pragma unroll
+                for (int u = 0; u < STEP; ++u) acc.step(t0[u * pitch], tb[2 * (j0 + u)], tb[2 * (j0 + u) + 1]);
+            }
         }
     } else {
         const int e0 = STEP * m + kSps * il;
+        if (SHARED && scalar_table) {
 #pragma unroll 8
-        for (int j = 0; j < kSps; ++j) {
-            const int e = e0 + j;
-            acc.step(tile[(e % STEP) * pitch + e / STEP], tb[2 * j], tb[2 * j + 1]);
+            for (int j = 0; j < kSps; ++j) {
+                const int e = e0 + j;
+                acc.step(tile[(e % STEP) * pitch + e / STEP], gtab[2 * j], gtab[2 * j + 1]);
+            }
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < kSps; ++j) {
+                const int e = e0 + j;
+                acc.step(tile[(e % STEP) * pitch + e / STEP], tb[2 * j], tb[2 * j + 1]);
+            }
         }
     }
     pw_out[((size_t)item * nlag + m) * kNSymD + i0 + il] = acc.amplitudes();
@@ -659,16 +681,17 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     };
     auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
+    static const int scalar_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return (e && e[0] == 'l') ? 0 : 1; }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0)                                                                                        \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
                                threads(kTileSymsShared), 8192 + tile_bytes(kTileSymsShared), st, dI, dQ, samples, \
-                               items, list_shared, mode, nlag, minsync1, tabs, pw4);                             \
+                               items, list_shared, mode, nlag, minsync1, tabs, pw4, scalar_tab);                 \
         if (n_own > 0)                                                                                           \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSymsOwn, n_own),             \
                                threads(kTileSymsOwn), kTileSymsOwn * 8192 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
-                               samples, items, list_own, mode, nlag, minsync1, tabs, pw4);                       \
+                               samples, items, list_own, mode, nlag, minsync1, tabs, pw4, 0);                    \
     } while (0)
     if (lagstep == 8) WSPR_LAUNCH_TILE(8);
     else if (lagstep == 16) WSPR_LAUNCH_TILE(16);
