@@ -608,7 +608,9 @@ struct Context::DecodeRun {
     const FanoMemo* memo = nullptr;           // results already known (re-decode after a late success)
 
     // one Fano attempt on a soft-symbol vector in transmission order (wsprd.c:759-761)
-    int fano_attempt(const unsigned char* tx_sym, unsigned* cycles, unsigned char* data11) const {
+    // ladder = an attempt on rungs 1..42 (those rarely decode: with the budget split on they get the shorter
+    // host budget `fast_ladder` before they are left to the device tail)
+    int fano_attempt(const unsigned char* tx_sym, unsigned* cycles, unsigned char* data11, bool ladder = false) const {
         memset(data11, 0, 11);
         if (memo)
             if (const FanoMemo::Entry* e = memo->find(tx_sym)) {
@@ -620,7 +622,8 @@ struct Context::DecodeRun {
         memcpy(sym, tx_sym, kNSymD);
         deinterleave162(sym);
         unsigned metric, maxnp;
-        return fano_decode(&metric, cycles, &maxnp, data11, sym, kNBits, met.tab, delta, maxcycles);
+        return fano_decode(&metric, cycles, &maxnp, data11, sym, kNBits, met.tab, delta,
+                           (ladder && fast) ? std::min(maxcycles, fast_ladder) : maxcycles);
     }
 
     // tuning constants of wsprd.c:423-433
@@ -630,6 +633,7 @@ struct Context::DecodeRun {
     const float minrms = 52.0 * (50 / 64.0);
     const int delta = 60;
     const unsigned maxcycles;
+    const unsigned fast_ladder = [] { const char* e = getenv("WSPR_FANO_FAST_LADDER"); return e ? (unsigned)atoi(e) : 10000u; }();
     const int lagstep, nlag0, njit_rest;
     const FanoMetrics& met = default_metrics();
 
@@ -937,7 +941,7 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             if (r > first[a].load()) return;           // an earlier rung already decoded
             const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
             if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
-            const int nd = fano_attempt(h_sym + g * kNSymD, &at.cycles, at.data);
+            const int nd = fano_attempt(h_sym + g * kNSymD, &at.cycles, at.data, true);
             at.pending = (nd != 0) && fast;
             if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
             if (nd == 0) {
