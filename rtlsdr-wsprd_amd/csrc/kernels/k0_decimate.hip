@@ -76,8 +76,7 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
 
     // all sums are modulo 2^32 (the reference's int32 integrators wrap): unsigned math
     unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // A: SI SQ WI WQ, B: SI SQ WI WQ
-    for (long v = v_lo + tid; v < v_hi && v < v_max; v += 256) {
-        const uint4 q = vec[v];                                   // rows are allocated in whole vectors
+    auto process = [&](long v, const uint4 q) {
         const long n0 = 8 * v;
         const int idx0 = (int)(n0 - first);
         const bool fullA = (idx0 >= 0) && (idx0 + 7 < kR) && (n0 + 7 < last);
@@ -120,7 +119,7 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
             const unsigned mA = fullA ? 1u : 0u, mB = fullA ? 0u : 1u;
             acc[0] += mA * (unsigned)tI;  acc[1] += mA * (unsigned)tQ;  acc[2] += mA * wI;  acc[3] += mA * wQ;
             acc[4] += mB * (unsigned)tI;  acc[5] += mB * (unsigned)tQ;  acc[6] += mB * wI;  acc[7] += mB * wQ;
-            continue;
+            return;
         }
         const unsigned wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -145,6 +144,24 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
             acc[2] += mA * wgt * ui;  acc[3] += mA * wgt * uq;
             acc[4] += mB * ui;        acc[5] += mB * uq;
             acc[6] += mB * wgt * ui;  acc[7] += mB * wgt * uq;
+        }
+    };
+    // a pair of blocks is ~1600 vectors, 6-7 per thread: four loads are issued before the first is used, so
+    // that a workgroup keeps 16 KB in flight instead of 4 (the stream needs ~10 MB outstanding chip-wide)
+    const long v_end = min(v_hi, v_max);
+    for (long v0 = v_lo + tid; v0 < v_end; v0 += 4 * 256) {
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long v = v0 + 256 * u;
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(vec) + ((v < v_end) ? v : v_lo));   // rows are allocated in whole vectors
+            q[u] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long v = v0 + 256 * u;
+            if (v < v_end) process(v, q[u]);
         }
     }
     const int wave = tid >> 6, lane = tid & 63;

@@ -212,6 +212,10 @@ struct ToneAcc {
 
 constexpr int kTileSymsShared = 9;    // 9 x 33 lags = 297 of 320 lanes; 28 KB of LDS
 constexpr int kTileSymsOwn = 6;       // per-symbol tables: 6 x 8 KB + tile
+// A wave of the per-symbol-table variant spans two or three symbols, whose tables are read at the same step
+// j: with a pitch of exactly 8 KB those reads fall on the same LDS banks (measured: bank-conflict cycles 1.5x
+// the LDS cycles of the kernel).  Two extra 16-byte words per table move consecutive symbols 8 banks apart.
+constexpr int kOwnTabPitch = 512 + 2;           // float4 words per table in LDS
 
 __global__ __launch_bounds__(64)
 void phasor_table_kernel(const FineState* __restrict__ items, int mode, float* __restrict__ tabs) {
@@ -252,9 +256,8 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     constexpr int kTileSyms = SHARED ? kTileSymsShared : kTileSymsOwn;
     const int i0 = blockIdx.x * kTileSyms, tid = threadIdx.x;
     const int lag0 = (mode == 0) ? st.shift_coarse - 128 : st.shift - 63;
-    constexpr int ntab = SHARED ? 1 : kTileSyms;
     float4* tab = reinterpret_cast<float4*>(smem);
-    float2* tile = reinterpret_cast<float2*>(smem + ntab * 8192);
+    float2* tile = reinterpret_cast<float2*>(smem + (SHARED ? 8192 : kTileSyms * kOwnTabPitch * 16));
     const int span = kSps * kTileSyms + STEP * (nlag - 1);
     const int pitch = (span + STEP - 1) / STEP + 1;
 
@@ -288,7 +291,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
             const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
             const float dphi = (float)(kTwoPiDt * ((double)fp + off));
             const float cd = glibc_cosf(dphi), sd = glibc_sinf(dphi);
-            float* __restrict__ t = reinterpret_cast<float*>(tab + il * 512);     // [256][8]
+            float* __restrict__ t = reinterpret_cast<float*>(tab + il * kOwnTabPitch);     // [256][8]
             float c = 1.0f, s = 0.0f;
             for (int j = 0; j < kSps; ++j) {
                 if (j > 0) {
@@ -319,7 +322,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
 
     const int il = tid / nlag, m = tid - il * nlag;
     if (il >= kTileSyms) return;
-    const float4* __restrict__ tb = tab + (SHARED ? 0 : il * 512);
+    const float4* __restrict__ tb = tab + (SHARED ? 0 : il * kOwnTabPitch);
     ToneAcc acc;
     acc.clear();
     if constexpr (STEP == 8 || STEP == 16) {
@@ -690,7 +693,7 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                                items, list_shared, mode, nlag, minsync1, tabs, pw4, scalar_tab);                 \
         if (n_own > 0)                                                                                           \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSymsOwn, n_own),             \
-                               threads(kTileSymsOwn), kTileSymsOwn * 8192 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
+                               threads(kTileSymsOwn), kTileSymsOwn * kOwnTabPitch * 16 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
                                samples, items, list_own, mode, nlag, minsync1, tabs, pw4, 0);                    \
     } while (0)
     if (lagstep == 8) WSPR_LAUNCH_TILE(8);
