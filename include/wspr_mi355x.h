@@ -74,9 +74,10 @@ int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options op
  * segments, planar host buffers idat/qdat[s*seg_stride + i]; results for segment s
  * go to decodes[s*max_results ...], n_results[s]: a segment's unique spots are ranked by SNR first and
  * the strongest max_results are returned (the reference allows 100, its caller holds 50).  Inputs are not
- * modified unless writeback != 0.  options.usehashtable must be 0 when nseg > 1: the hash memory orders
- * the segments and a batch decodes them concurrently -- such a call is refused with -2 (all n_results 0,
- * message on stderr), never silently decoded without the option. */
+ * modified unless writeback != 0.  With options.usehashtable the hash memory orders the segments
+ * (wsprd.c:481-494, 842-852), so the batch is decoded one segment at a time in index order, each exactly
+ * like a reference call (hashtable.txt read before, written after): same spots as nseg calls of
+ * wspr_decode(), without the batch parallelism. */
 int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results *decodes,
                       int max_results, int *n_results, int writeback);
@@ -124,6 +125,32 @@ int wspr_decimate_u8_stream(wspr_decim_state *st, const uint8_t *iq, size_t nbyt
 int wspr_decimate_u8_batch_device_stateful(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_states,
                                            void *d_idat, void *d_qdat, int *n_out);
 size_t wspr_iq_stride(void);        /* floats per segment row of device IQ buffers */
+
+/* ---- receiver session --------------------------------------------------------------------
+ * The reference's rx_state (two I/Q buffers of 45000 samples, their fill counters, the active index,
+ * rtlsdr_wsprd.c:78-90), the decimator's static state (:135-160) and the body of its decoder thread (:263-328) as
+ * one object.  The application keeps its three threads: the RX thread feeds librtlsdr callback buffers, the main
+ * loop rolls the buffers over on the even minute, the decoder thread decodes the completed buffer.  feed() may
+ * run beside decode() (they touch different buffers; the front end runs on its own lane of the library). */
+typedef struct wspr_session wspr_session;
+wspr_session *wspr_session_create(struct decoder_options options);     /* initSampleStorage(), :331-336 */
+void wspr_session_destroy(wspr_session *s);
+/* rtlsdr_callback(buf, len), :126-244: mixer + CIC + FIR into the active buffer (outputs beyond 45000 are
+ * dropped, :236-242).  len a multiple of 16 (librtlsdr delivers 65536).  Returns the buffer's fill, < 0 on error. */
+int wspr_session_feed(wspr_session *s, const uint8_t *buf, uint32_t len);
+/* Main loop on the 2-minute boundary, :1179-1182: switches to the other buffer (fill reset to 0) and returns the
+ * index of the buffer that just completed. */
+int wspr_session_rollover(wspr_session *s);
+/* decoder(), :263-328, on a completed buffer: returns 0 without decoding if it holds fewer than 117 s of samples
+ * (:277), else zeroes the tail (:284-288), normalises to a peak of 0.5 (:290-305), calls wspr_decode() (:312-317)
+ * and returns 1 (negative: no usable device).  The buffer then holds what the reference's saveSample() would see. */
+int wspr_session_decode(wspr_session *s, int buffer, struct decoder_results *decodes, int *n_results);
+uint32_t wspr_session_fill(const wspr_session *s, int buffer);
+const float *wspr_session_samples(const wspr_session *s, int buffer, int rail /* 0 = I, 1 = Q */);
+/* Microseconds until the next even UTC minute, :1170-1175 (what the main loop sleeps). */
+uint32_t wspr_usec_to_next_slot(long tv_sec, long tv_usec);
+/* UTC time stamp of the frame being decoded: gmtime(now - 120 + 1), :307-310; for wspr_format_spot_timestamped(). */
+void wspr_frame_time(long unixtime_now, int *year, int *month, int *day, int *hour, int *minute);
 
 /* ---- recorded files and the playback print format ----------- */
 /* Replaces readRawIQfile(), reference rtlsdr_wsprd.c:555-592 (.iq: interleaved f32, Q negated,

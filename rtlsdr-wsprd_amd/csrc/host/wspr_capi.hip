@@ -7,6 +7,9 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <atomic>
+#include <ctime>
+#include <new>
 #include <vector>
 
 #include "wspr_message.h"
@@ -29,13 +32,18 @@ int fail(const char* where, const std::exception& e) {
     return -1;
 }
 // The callsign hash memory makes a segment's result depend on what was decoded before it
-// (wsprd.c:481-494, 842-852); segments of a batch are decoded concurrently, so the option is honoured for
-// single-segment calls only and REFUSED -- not silently dropped -- for batches.
-int refuse_hashtable_batch(const char* where, int nseg, int* n_results) {
-    for (int s = 0; s < nseg; ++s) n_results[s] = 0;
-    fprintf(stderr, "libwspr_mi355x: %s: usehashtable = 1 is only defined for one segment per call "
-                    "(hashtable.txt orders the calls); decode the segments one by one or clear the option\n", where);
-    return -2;
+// (wsprd.c:481-494, 842-852: hashtable.txt read before, written after every decode).  Segments of a batch are
+// normally decoded concurrently; with usehashtable = 1 they are therefore decoded ONE BY ONE IN ORDER, each
+// as the reference's own call would be (load the file, decode, save the file) -- the option is honoured, not
+// dropped, at the price of the batch parallelism.
+template <class One>
+int decode_in_order(int nseg, int* n_results, One one) {
+    int rc = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int r = one(s);
+        if (r < 0) { rc = r; for (int k = s; k < nseg; ++k) n_results[k] = 0; break; }
+    }
+    return rc;
 }
 // device scratch of one call, released on every exit path
 struct TempDev {
@@ -114,7 +122,11 @@ size_t wspr_iq_stride(void) { return (size_t)wspr::kIqStride; }
 int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results* decodes, int max_results,
                       int* n_results, int writeback) {
-    if (options.usehashtable && nseg > 1) return refuse_hashtable_batch("wspr_decode_batch", nseg, n_results);
+    if (options.usehashtable && nseg > 1)
+        return decode_in_order(nseg, n_results, [&](int s) {
+            return wspr_decode_batch(idat + (size_t)s * seg_stride, qdat + (size_t)s * seg_stride, 1, samples, seg_stride,
+                                     options, decodes + (size_t)s * max_results, max_results, n_results + s, writeback);
+        });
     try {
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
@@ -134,7 +146,12 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
 int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results) {
-    if (options.usehashtable && nseg > 1) return refuse_hashtable_batch("wspr_decode_batch_device", nseg, n_results);
+    if (options.usehashtable && nseg > 1)
+        return decode_in_order(nseg, n_results, [&](int s) {
+            return wspr_decode_batch_device(static_cast<const float*>(d_idat) + (size_t)s * seg_stride,
+                                            static_cast<const float*>(d_qdat) + (size_t)s * seg_stride, 1, samples, seg_stride,
+                                            options, decodes + (size_t)s * max_results, max_results, n_results + s);
+        });
     try {
         if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
         const float* di = static_cast<const float*>(d_idat);
@@ -364,6 +381,117 @@ int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint3
         return 0;
     } catch (const std::exception& e) { return fail("wspr_decimate_u8", e); }
 }
+
+// ---- receiver session: the reference's double buffer and decoder thread body ----------------
+// rx_state of rtlsdr_wsprd.c:78-90 (two I/Q buffers, their fill counters, the active index) plus the
+// decimator's static state (:135-160), as one object the application drives from its own threads:
+//   RX thread       wspr_session_feed()      = rtlsdr_callback()                       (:126-244)
+//   main loop       wspr_session_rollover()  = switch buffers on the even minute       (:1179-1182)
+//   decoder thread  wspr_session_decode()    = decoder(): too-short check, zero the tail, normalise, decode (:263-328)
+struct wspr_session {
+    decoder_options opt;
+    wspr::DecimState dec;                      // all zero = the receiver at start-up
+    std::vector<float> I[2], Q[2];
+    std::atomic<uint32_t> fill[2];
+    std::atomic<uint32_t> active;
+};
+
+namespace {
+constexpr uint32_t kSessionSamples = 120 * 375;              // SIGNAL_LENGHT * SIGNAL_SAMPLE_RATE
+constexpr uint32_t kSessionMinSamples = (120 - 3) * 375;     // rtlsdr_wsprd.c:277
+constexpr int kFrontEndLane = Context::kMaxLanes - 1;        // feed() runs beside decode(): its own lane
+}  // namespace
+
+extern "C" {
+
+wspr_session* wspr_session_create(struct decoder_options options) {
+    wspr_session* s = new (std::nothrow) wspr_session;
+    if (!s) return nullptr;
+    s->opt = options;
+    std::memset(&s->dec, 0, sizeof s->dec);
+    for (int b = 0; b < 2; ++b) {
+        s->I[b].assign(kSessionSamples, 0.0f);
+        s->Q[b].assign(kSessionSamples, 0.0f);
+        s->fill[b].store(0);
+    }
+    s->active.store(0);                                     // initSampleStorage(), rtlsdr_wsprd.c:331-336
+    return s;
+}
+
+void wspr_session_destroy(wspr_session* s) { delete s; }
+
+int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
+    if (!s || !buf || (len & 15u)) return -1;
+    const int caller_lane = Context::lane();
+    try {
+        Context::bind_lane(kFrontEndLane);
+        const uint32_t idx = s->active.load();
+        uint32_t nf = s->fill[idx].load();
+        const int rc = Context::get().decimate_stream(&s->dec, buf, len, s->I[idx].data(), s->Q[idx].data(), nf,
+                                                      kSessionSamples, &nf);           // :236-242: full buffer drops the rest
+        Context::bind_lane(caller_lane);
+        if (rc) return rc;
+        s->fill[idx].store(nf);
+        return (int)nf;
+    } catch (const std::exception& e) {
+        Context::bind_lane(caller_lane);
+        return fail("wspr_session_feed", e);
+    }
+}
+
+int wspr_session_rollover(wspr_session* s) {
+    if (!s) return -1;
+    const uint32_t prev = s->active.load(), next = prev ^ 1u;
+    s->fill[next].store(0);                                 // rx_state.iqIndex[rx_state.bufferIndex] = 0
+    s->active.store(next);
+    return (int)prev;
+}
+
+uint32_t wspr_session_fill(const wspr_session* s, int buffer) { return (s && (buffer & ~1) == 0) ? s->fill[buffer].load() : 0u; }
+
+const float* wspr_session_samples(const wspr_session* s, int buffer, int rail) {
+    if (!s || (buffer & ~1) != 0) return nullptr;
+    return rail ? s->Q[buffer].data() : s->I[buffer].data();
+}
+
+int wspr_session_decode(wspr_session* s, int buffer, struct decoder_results* decodes, int* n_results) {
+    if (!s || (buffer & ~1) != 0 || !n_results) return -1;
+    *n_results = 0;
+    const uint32_t n = s->fill[buffer].load();
+    if (n < kSessionMinSamples) return 0;                  // "Signal too short, skipping!" (:277-280)
+    float* I = s->I[buffer].data();
+    float* Q = s->Q[buffer].data();
+    for (uint32_t i = n; i < kSessionSamples; ++i) { I[i] = 0.0f; Q[i] = 0.0f; }     // :284-288
+    float peak = 1e-24f;                                    // :290-305
+    for (uint32_t i = 0; i < kSessionSamples; ++i) {
+        const float a = fabsf(I[i]), b = fabsf(Q[i]);
+        if (a > peak) peak = a;
+        if (b > peak) peak = b;
+    }
+    const float scale = (float)(0.5 / (double)peak);
+    for (uint32_t i = 0; i < kSessionSamples; ++i) { I[i] *= scale; Q[i] *= scale; }
+    const int rc = wspr_decode(I, Q, (int)kSessionSamples, s->opt, decodes, n_results);   // :312-317
+    return rc < 0 ? rc : 1;
+}
+
+uint32_t wspr_usec_to_next_slot(long tv_sec, long tv_usec) {                              // :1170-1175
+    const uint32_t sec = (uint32_t)(tv_sec % 120);
+    const uint32_t usec = sec * 1000000u + (uint32_t)tv_usec;
+    return 120000000u - usec;
+}
+
+void wspr_frame_time(long unixtime_now, int* year, int* month, int* day, int* hour, int* minute) {   // :307-310
+    time_t t = (time_t)unixtime_now - 120 + 1;
+    struct tm g;
+    gmtime_r(&t, &g);
+    if (year) *year = g.tm_year + 1900;
+    if (month) *month = g.tm_mon + 1;
+    if (day) *day = g.tm_mday;
+    if (hour) *hour = g.tm_hour;
+    if (minute) *minute = g.tm_min;
+}
+
+}  // extern "C"
 
 // ---- recorded-file formats ----------------------------------------
 namespace {

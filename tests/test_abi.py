@@ -39,24 +39,6 @@ def test_library_exports_nothing_but_the_declared_symbols():
     assert exported == funcs | data, (sorted(exported - funcs - data), sorted((funcs | data) - exported))
 
 
-def test_hashtable_option_on_a_batch_is_refused_not_dropped(capfd):
-    """usehashtable orders the segments (wsprd.c:481-494, 842-852); a batch decodes them concurrently, so
-    the call is refused loudly -- before any device work, hence checkable without a GPU."""
-    import numpy as np
-    L = w.lib()
-    z = np.zeros((2, 45000), np.float32)
-    opt = w.default_options()
-    opt.usehashtable = 1
-    out = (w.decoder_results * 8)()
-    n = (C.c_int * 2)(7, 7)
-    rc = L.wspr_decode_batch(z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 2, 45000, 45000, opt,
-                             C.addressof(out), 4, C.addressof(n), 0)
-    assert rc == -2 and list(n) == [0, 0]
-    assert "usehashtable" in capfd.readouterr().err
-    rc = L.wspr_decode_batch_device(None, None, 2, 45000, 45056, opt, C.addressof(out), 4, C.addressof(n))
-    assert rc == -2
-
-
 def test_set_device_rejects_devices_that_do_not_exist():
     L = w.lib()
     L.wspr_device_count.restype = C.c_int

@@ -79,3 +79,35 @@ def test_daemon_line_and_wsprnet_url_formats():
     L.wspr_format_wsprnet_url(None, C.addressof(opt), 14095600.0, 2026, 9, 28, 1, 30, b"rtlsdr-056", buf, 600)
     assert buf.value.decode() == ("https://wsprnet.org/post?function=wsprstat&rcall=VA2GKA%2FP&rgrid=FN35&rqrg=14.095600&tpct=0.00"
                                   "&tqrg=14.095600&dbm=0&version=rtlsdr-056&mode=2")
+
+
+def test_slot_timing_helpers():
+    """Main-loop sleep (rtlsdr_wsprd.c:1170-1175) and the frame's time stamp gmtime(now - 120 + 1) (:307-310)."""
+    L = w.lib()
+    L.wspr_usec_to_next_slot.restype = C.c_uint32
+    L.wspr_usec_to_next_slot.argtypes = [C.c_long, C.c_long]
+    assert L.wspr_usec_to_next_slot(1200, 0) == 120000000
+    assert L.wspr_usec_to_next_slot(1200 + 119, 999999) == 1
+    assert L.wspr_usec_to_next_slot(1790567424, 437248) == 120000000 - ((1790567424 % 120) * 1000000 + 437248)
+    L.wspr_frame_time.argtypes = [C.c_long] + [C.c_void_p] * 5
+    v = [C.c_int() for _ in range(5)]
+    L.wspr_frame_time(1790567520, *[C.byref(x) for x in v])        # 2026-09-28 04:32:00 UTC
+    import datetime
+    t = datetime.datetime.fromtimestamp(1790567520 - 120 + 1, datetime.timezone.utc)
+    assert [x.value for x in v] == [t.year, t.month, t.day, t.hour, t.minute]
+    # a session object exists without a GPU; an empty buffer is "too short": nothing is decoded, nothing fails
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    s = L.wspr_session_create(w.default_options())
+    assert s
+    L.wspr_session_rollover.argtypes = [C.c_void_p]
+    L.wspr_session_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_fill.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_session_fill.restype = C.c_uint32
+    assert L.wspr_session_rollover(s) == 0 and L.wspr_session_rollover(s) == 1
+    n = C.c_int(5)
+    out = (w.decoder_results * 50)()
+    assert L.wspr_session_decode(s, 0, C.addressof(out), C.byref(n)) == 0 and n.value == 0
+    assert L.wspr_session_fill(s, 0) == 0
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    L.wspr_session_destroy(s)

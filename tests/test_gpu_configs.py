@@ -207,3 +207,66 @@ def test_bench_rccl_path_world_size_one():
     assert d["n_gpus"] == 1 and ok >= 0.95 * sent and d["false_decodes"] == 0
     assert d["spots_total"] >= ok                      # counted from the GATHERED records
     assert d["config"]["gathered_over"] == "rccl"
+
+
+# ------------------------------------------------------------------ receiver session (f4)
+def test_receiver_session_two_minute_flow(env):
+    """The reference's receive loop through the session object: one full 2-minute raw segment arrives in
+    librtlsdr callback buffers (65 536 bytes), the buffers roll over, the completed buffer is decoded; the next
+    slot only receives a few callbacks and is skipped as too short (rtlsdr_wsprd.c:126-244, 263-328, 1179-1182).
+    Decimated IQ, spots and the carried decimator state equal the oracle fed with the same callbacks."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    raw, exp = bench.synth_raw_gpu(1, 61, dev, -18.0)
+    host = raw[0].cpu().numpy()
+    extra = bench.synth_raw_gpu(1, 62, dev, -18.0)[0][0][: 65536 * 40].cpu().numpy()      # the start of the next slot
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_rollover.argtypes = [C.c_void_p]
+    L.wspr_session_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_fill.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_session_fill.restype = C.c_uint32
+    L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.wspr_session_samples.restype = C.POINTER(C.c_float)
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    s = L.wspr_session_create(w.default_options(freq=14095600))
+    O = ol.lib()
+    ost = O.orc_decim_new()
+    oi = [np.zeros(NS, np.float32), np.zeros(NS, np.float32)]
+    oq = [np.zeros(NS, np.float32), np.zeros(NS, np.float32)]
+    ofill = 0
+    CB = 65536
+    for pos in range(0, host.size, CB):
+        chunk = np.ascontiguousarray(host[pos:pos + CB])
+        fill = L.wspr_session_feed(s, ol.ptr(chunk), chunk.size)
+        ofill = O.orc_decim_feed(C.c_void_p(ost), ol.ptr(chunk), chunk.size, ol.ptr(oi[0]), ol.ptr(oq[0]), ofill, NS)
+        assert fill == ofill, pos
+    assert ofill == 44992
+    done = L.wspr_session_rollover(s)
+    assert done == 0 and L.wspr_session_fill(s, 1) == 0
+    # the RX thread keeps feeding the other buffer while the decoder works on the completed one
+    ofill1 = 0
+    for pos in range(0, extra.size, CB):
+        chunk = np.ascontiguousarray(extra[pos:pos + CB])
+        fill = L.wspr_session_feed(s, ol.ptr(chunk), chunk.size)
+        ofill1 = O.orc_decim_feed(C.c_void_p(ost), ol.ptr(chunk), chunk.size, ol.ptr(oi[1]), ol.ptr(oq[1]), ofill1, NS)
+        assert fill == ofill1
+    out = (w.decoder_results * 50)()
+    n = C.c_int(0)
+    assert L.wspr_session_decode(s, done, C.addressof(out), C.byref(n)) == 1
+    O.orc_normalise(ol.ptr(oi[0]), ol.ptr(oq[0]), C.c_int(ofill), C.c_int(NS))
+    ref, ri, rq = ol.decode(oi[0], oq[0], NS, ol.default_options(freq=14095600))
+    assert _same_as_oracle([out[k] for k in range(n.value)], ref) and n.value >= 1
+    assert [out[k].message.decode() for k in range(n.value)][0] == exp[0][0]
+    gi = np.ctypeslib.as_array(L.wspr_session_samples(s, done, 0), shape=(NS,))
+    gq = np.ctypeslib.as_array(L.wspr_session_samples(s, done, 1), shape=(NS,))
+    assert np.array_equal(gi, ri) and np.array_equal(gq, rq)          # the residual saveSample() would write
+    # the second slot is only 40 callbacks long: the carried state gave the same samples as the oracle's stream ...
+    g1 = np.ctypeslib.as_array(L.wspr_session_samples(s, 1, 0), shape=(NS,))
+    assert ofill1 > 100 and np.array_equal(g1[:ofill1], oi[1][:ofill1])
+    # ... and the decoder skips it (fewer than 117 s of samples)
+    assert L.wspr_session_rollover(s) == 1
+    assert L.wspr_session_decode(s, 1, C.addressof(out), C.byref(n)) == 0 and n.value == 0
+    O.orc_decim_free(C.c_void_p(ost))
+    L.wspr_session_destroy(s)

@@ -577,3 +577,36 @@ def test_decode_after_set_device(w, ref_iq):
     spots, _, _ = w.wspr_decode(ref_iq[0], ref_iq[1], NS)
     assert [s.message for s in spots] == [b"K1JT FN20 20"]
     assert L.wspr_set_device(L.wspr_device_count()) == -1
+
+
+def test_hashtable_option_on_a_batch_decodes_in_order(w, tmp_path):
+    """usehashtable = 1 on a batch: segments are decoded one by one in index order, each like a reference call
+    (hashtable.txt read before, written after, wsprd.c:481-494, 842-852).  Segment 0 carries the compound call
+    (type 2), segments 1 and 2 only its hashed form (type 3): they resolve <...> because of segment 0.
+    Same spots and same hashtable.txt as the oracle called three times, and as three single product calls."""
+    segs = [_multi_segment(["PJ4/K1ABC 37"], 51), _multi_segment(["<PJ4/K1ABC> FK52UD 37", "W1AW FN31 10"], 52),
+            _multi_segment(["<PJ4/K1ABC> FK52UD 37"], 53)]
+    I = np.stack([s[0] for s in segs]); Q = np.stack([s[1] for s in segs])
+    cwd = os.getcwd()
+    res = {}
+    try:
+        for mode in ("batch", "singles", "oracle"):
+            d = tmp_path / mode
+            d.mkdir()
+            os.chdir(d)
+            if mode == "batch":
+                got = w.wspr_decode_batch(I, Q, _opt(w, 1))
+                res[mode] = [[_spot_tuple(x) for x in g] for g in got]
+            elif mode == "singles":
+                res[mode] = [[_spot_tuple(x) for x in w.wspr_decode(I[s], Q[s], NS, _opt(w, 1))[0]] for s in range(3)]
+            else:
+                res[mode] = [[_spot_tuple(x) for x in ol.decode(I[s], Q[s], NS, _oopt(1))[0]] for s in range(3)]
+            res[mode + "_file"] = open("hashtable.txt").read()
+    finally:
+        os.chdir(cwd)
+    assert res["batch"] == res["singles"] == res["oracle"]
+    assert res["batch_file"] == res["singles_file"] == res["oracle_file"] and "PJ4/K1ABC" in res["batch_file"]
+    assert [m[0] for m in res["batch"][2]] == [b"<PJ4/K1ABC> FK52UD 37"]
+    # without the option the hashed call cannot be resolved in a fresh batch
+    plain = w.wspr_decode_batch(I, Q, _opt(w, 0))
+    assert [x.message for x in plain[2]] != [b"<PJ4/K1ABC> FK52UD 37"]
