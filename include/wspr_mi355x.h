@@ -125,6 +125,9 @@ int wspr_decimate_u8_stream(wspr_decim_state *st, const uint8_t *iq, size_t nbyt
 int wspr_decimate_u8_batch_device_stateful(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_states,
                                            void *d_idat, void *d_qdat, int *n_out);
 size_t wspr_iq_stride(void);        /* floats per segment row of device IQ buffers */
+/* The front end's constants as the kernels use them: the 33 compensation-FIR taps (zCoef, reference
+ * rtlsdr_wsprd.c:142-152) and the input samples per output (DOWNSAMPLING + 1 = 6401, :41, :198-202). */
+void wspr_front_end_constants(float *taps33, int *samples_per_output);
 
 /* ---- receiver session --------------------------------------------------------------------
  * The reference's rx_state (two I/Q buffers of 45000 samples, their fill counters, the active index,

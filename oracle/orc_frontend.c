@@ -27,6 +27,8 @@ static const float fir_half[17] = {
      0.5000000000f
 };
 
+#define ORC_DOWNSAMPLING (2400000u / 375u)     /* SAMPLING_RATE / SIGNAL_SAMPLE_RATE, rtlsdr_wsprd.c:36-41 */
+
 struct orc_decim_state {
     uint32_t i1, i2, q1, q2;            /* integrators (mod 2^32)           */
     uint32_t ic1[2], ic2[2];            /* comb delay lines, I              */
@@ -43,6 +45,13 @@ orc_decim_state *orc_decim_new(void) {
     return s;
 }
 void orc_decim_free(orc_decim_state *s) { free(s); }
+
+/* the constants of the front end as this restatement uses them: 33 FIR taps (rtlsdr_wsprd.c:142-152) and the
+ * number of input samples per output (rtlsdr_wsprd.c:198-202: DOWNSAMPLING + 1) */
+void orc_front_end_constants(float *taps33, int *samples_per_output) {
+    for (int i = 0; i < 17; i++) { taps33[i] = fir_half[i]; taps33[32 - i] = fir_half[i]; }
+    *samples_per_output = (int)ORC_DOWNSAMPLING + 1;
+}
 
 static inline int8_t s8(unsigned char b) { return (int8_t)(b ^ 0x80); }
 static inline int8_t neg8(int8_t v) { return (int8_t)(uint8_t)(0u - (uint8_t)v); } /* -(-128) = -128 */
@@ -62,7 +71,7 @@ uint32_t orc_decim_feed(orc_decim_state *s, const unsigned char *iq, size_t nbyt
         s->i1 += (uint32_t)(int32_t)xi;  s->q1 += (uint32_t)(int32_t)xq;
         s->i2 += s->i1;                  s->q2 += s->q1;
         /* decimate by 6401, :197-202 */
-        if (++s->phase <= 6400u) continue;
+        if (++s->phase <= ORC_DOWNSAMPLING) continue;      /* decimationIndex <= DOWNSAMPLING, then reset */
         s->phase = 0;
         /* two combs with a two-output delay, :204-218 */
         uint32_t iy1 = s->i2 - s->ic1[1];  s->ic1[1] = s->ic1[0];  s->ic1[0] = s->i2;

@@ -144,6 +144,7 @@ void   orc_decim_free(orc_decim_state *);
 uint32_t orc_decim_feed(orc_decim_state *, const unsigned char *iq, size_t nbytes,
                         float *I, float *Q, uint32_t fill, uint32_t cap);
 void   orc_normalise(float *I, float *Q, int n_valid, int n_total);
+void   orc_front_end_constants(float *taps33, int *samples_per_output);
 /* .iq file semantics: interleaved f32 -> planar with Q negated, then normalise */
 int    orc_iq_from_interleaved(const float *file_f32, int nfloats, float *I, float *Q);
 

@@ -350,6 +350,8 @@ int wspr_decimate_u8_batch_device_stateful(const void* d_raw, size_t bytes_per_s
     } catch (const std::exception& e) { return fail("wspr_decimate_u8_batch_device_stateful", e); }
 }
 
+void wspr_front_end_constants(float* taps33, int* samples_per_output) { wspr::front_end_constants(taps33, samples_per_output); }
+
 void wspr_decim_stream_reset(wspr_decim_state* st) {
     if (st) std::memset(st, 0, sizeof *st);
 }

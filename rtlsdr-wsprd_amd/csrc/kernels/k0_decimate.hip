@@ -34,13 +34,15 @@ namespace {
 
 constexpr int kR = 6401;                 // decimation ratio (DOWNSAMPLING + 1)
 
-__constant__ float kFirTaps[33] = {      // rtlsdr_wsprd.c:142-152
-    -0.0027772683f, -0.0005058826f, 0.0049745750f, -0.0034059318f, -0.0077557814f, 0.0139375423f,
-    0.0039896935f,  -0.0299394142f, 0.0162250643f, 0.0405130860f,  -0.0580746013f, -0.0272104968f,
-    0.1183705475f,  -0.0306029022f, -0.2011241667f, 0.1615898423f, 0.5000000000f,  0.1615898423f,
-    -0.2011241667f, -0.0306029022f, 0.1183705475f, -0.0272104968f, -0.0580746013f, 0.0405130860f,
-    0.0162250643f,  -0.0299394142f, 0.0039896935f, 0.0139375423f,  -0.0077557814f, -0.0034059318f,
-    0.0049745750f,  -0.0005058826f, -0.0027772683f};
+#define WSPR_FIR_TAPS {      /* rtlsdr_wsprd.c:142-152 */                                                     \
+    -0.0027772683f, -0.0005058826f, 0.0049745750f, -0.0034059318f, -0.0077557814f, 0.0139375423f,             \
+    0.0039896935f,  -0.0299394142f, 0.0162250643f, 0.0405130860f,  -0.0580746013f, -0.0272104968f,            \
+    0.1183705475f,  -0.0306029022f, -0.2011241667f, 0.1615898423f, 0.5000000000f,  0.1615898423f,             \
+    -0.2011241667f, -0.0306029022f, 0.1183705475f, -0.0272104968f, -0.0580746013f, 0.0405130860f,             \
+    0.0162250643f,  -0.0299394142f, 0.0039896935f, 0.0139375423f,  -0.0077557814f, -0.0034059318f,            \
+    0.0049745750f,  -0.0005058826f, -0.0027772683f}
+__constant__ float kFirTaps[33] = WSPR_FIR_TAPS;
+const float kFirTapsHost[33] = WSPR_FIR_TAPS;
 
 __device__ __forceinline__ int s8(unsigned b) { return (int)(b & 0xffu) - 128; }        // (int8)(b ^ 0x80)
 __device__ __forceinline__ int neg8(int v) { return (v == -128) ? -128 : -v; }          // int8 negate
@@ -295,6 +297,11 @@ void cic_carry_kernel(const uint32_t* __restrict__ x2all, int nblocks, size_t se
 }  // namespace
 
 // blocks a chunk of nsamp samples can touch (scratch pitch); without a state only whole blocks count
+void front_end_constants(float* taps33, int* samples_per_output) {
+    for (int i = 0; i < 33; ++i) taps33[i] = kFirTapsHost[i];
+    *samples_per_output = kR;
+}
+
 int decimate_blocks(size_t nsamp, bool stateful) {
     return stateful ? (int)((nsamp + 2 * (size_t)kR - 2) / kR) : (int)(nsamp / kR);
 }

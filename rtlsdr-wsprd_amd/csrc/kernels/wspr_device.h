@@ -154,6 +154,7 @@ struct DecimState {
     uint32_t hist[2][kDecimHist];
 };
 int decimate_blocks(size_t nsamp, bool stateful);
+void front_end_constants(float* taps33, int* samples_per_output);   // the FIR taps and R as the kernels use them
 // states: null = zero state, whole blocks only; else one DecimState per segment row, read and updated
 void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ,
                      int* n_out, int32_t* scratch, hipStream_t st, DecimState* states = nullptr);

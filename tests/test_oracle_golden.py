@@ -252,3 +252,30 @@ def test_oracle_reproduces_committed_scene_spots():
         spots, _, _ = ol.decode(I, Q, scenes.NS)
         assert [scenes.spot_record(s) for s in spots] == g["spots"], g["seed"]
     assert sum(len(g["spots"]) for g in gold) >= 25
+
+
+# ------------------------------------------------------- front-end constants
+def test_front_end_constants_equal_the_reference_source():
+    """The decimator has no reference-held fixture (its translation unit needs librtlsdr/libcurl), so its
+    CONSTANTS at least are read out of the reference source where it is mounted and compared with what the
+    oracle and the product use: the 33 zCoef taps (rtlsdr_wsprd.c:142-152), SAMPLING_RATE / SIGNAL_SAMPLE_RATE
+    (:36-41) and the '<= DOWNSAMPLING' test that makes the ratio 6401 (:198-202).  Elsewhere (GPU box) the
+    product is compared with the oracle only."""
+    import re
+    import rtlsdr_wsprd_amd as w
+    ot = (C.c_float * 33)(); orr = C.c_int()
+    ol.lib().orc_front_end_constants(ot, C.byref(orr))
+    pt = (C.c_float * 33)(); pr = C.c_int()
+    w.lib().wspr_front_end_constants(pt, C.byref(pr))
+    assert list(ot) == list(pt) and orr.value == pr.value == 6401
+    src = "/root/reference/rtlsdr_wsprd.c"
+    if not os.path.exists(src):
+        pytest.skip("reference source not mounted here")
+    txt = open(src).read()
+    body = re.search(r"zCoef\[33\]\s*=\s*\{([^}]*)\}", txt).group(1)
+    taps = [np.float32(float(x)) for x in re.findall(r"-?\d+\.\d+", body)]
+    assert len(taps) == 33 and [float(t) for t in taps] == [float(np.float32(x)) for x in ot]
+    rate = int(re.search(r"#define\s+SAMPLING_RATE\s+(\d+)", txt).group(1))
+    out_rate = int(re.search(r"#define\s+SIGNAL_SAMPLE_RATE\s+(\d+)", txt).group(1))
+    assert re.search(r"decimationIndex\s*<=\s*DOWNSAMPLING", txt)          # <=, hence one more than the quotient
+    assert rate // out_rate + 1 == orr.value
