@@ -99,17 +99,27 @@ void pick_peaks_kernel(const float* __restrict__ psavg, const int* __restrict__ 
     }
     __syncthreads();
 
-    // 30th percentile = element 122 of the ascending sort (wsprd.c:576-583), by rank counting
-    if (tid < kSmooth) {
-        const float v = sm[tid];
-        int less = 0, leq = 0;
-        for (int j = 0; j < kSmooth; ++j) {
-            const float u = sm[j];
-            less += (u < v);
-            leq  += (u <= v);
+    // 30th percentile = element 122 of the ascending sort (wsprd.c:576-583).  Only the VALUE at that position
+    // is used, so any correct ascending sort gives the reference's number: a bitonic network over 512 LDS
+    // words (411 values + infinities), one compare-exchange per thread pair and step (45 steps; the rank
+    // counting of round 1 cost every thread 411 comparisons and was a fifth of the stage at 8 192 segments).
+    // Non-finite inputs only have to terminate: NaN fails every comparison and stays where it is.
+    __shared__ float srt[512];
+    srt[tid] = (tid < kSmooth) ? sm[tid] : __int_as_float(0x7f800000);
+    __syncthreads();
+    for (int len = 2; len <= 512; len <<= 1) {
+        for (int stride = len >> 1; stride > 0; stride >>= 1) {
+            if (tid < 256) {
+                const int lo = ((tid & ~(stride - 1)) << 1) | (tid & (stride - 1));
+                const int hi = lo | stride;
+                const bool up = (lo & len) == 0;                      // ascending block
+                const float a = srt[lo], b = srt[hi];
+                if ((a > b) == up) { srt[lo] = b; srt[hi] = a; }
+            }
+            __syncthreads();
         }
-        if (less <= 122 && 122 < leq) noise_s = v;
     }
+    if (tid == 0) noise_s = srt[122];
     __syncthreads();
     const float noise = noise_s;
 
