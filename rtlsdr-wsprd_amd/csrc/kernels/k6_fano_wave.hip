@@ -3,10 +3,10 @@
 // Replaces (for the decoder's long tail) reference wsprd/fano.c:87-238 + wsprd_utils.c:196-213.
 // The algorithm and its proof sketch are in fano_wave.h: the reference's serial walk is the
 // pre-order traversal of a tree of (node, threshold) visits; this kernel expands that tree 64
-// visits at a time from a stack kept in walk order in LDS, with per-visit ledgers that make the
+// visits at a time from a stack kept in walk order, with per-visit ledgers that make the
 // reference's cycle count come out exactly.  An undecodable vector (810 000 cycles in the
 // reference, ~5 ms of a CPU core, 0.5 s of one GPU lane in the serial kernel k6_fano_tail.hip)
-// takes ~8 700 steps here.
+// takes ~7 400 steps here (10 ms alone; 6 000 of them together: 18 ms).
 //
 // Per step (one wave, no divergence outside the three predicated store slots):
 //   pop     lanes read the n <= 64 earliest visits (structure-of-arrays stack, conflict-free)
@@ -14,7 +14,9 @@
 //   cut     a completed frame drops everything later in walk order
 //   scan    output slots by ballot/mbcnt; ledger flow by one DPP prefix sum + one bpermute
 //   push    children written back in walk order (top of the stack = earliest)
-// Integer work, LDS-latency bound; 21 KB of LDS per wave -> 7 waves per CU.
+// Integer work, latency bound.  The stack lives either in a per-wave slice of device memory (default:
+// 4 096 visits, L2-resident, 1.3 KB of LDS per wave -> 32 waves per CU) or in LDS (1 024 visits, 21 KB
+// per wave -> 7 waves per CU; the step narrows when the store fills).
 #include "wspr_device.h"
 #include "fano_wave.h"
 #include <cstdlib>
