@@ -228,7 +228,10 @@ def main():
     if use_dist:
         opt = wd.broadcast_options(opt, src=0)          # fan-out of the (tiny) job description
     cpus_here = int(os.environ["WSPR_HOST_THREADS"])
-    inflight = args.inflight if args.inflight else (2 if cpus_here >= 6 else 1)
+    # crowded band (configs[2]): the Fano attempts run on the device (library default for such batches), the host
+    # only keeps books, and four batches in flight cover the device round trips of a wave (25.5 / 25.9 / 27.2 k
+    # segments/s with 2 / 3 / 4 in flight; also with 2 host threads); otherwise two if the rank has the CPUs
+    inflight = args.inflight if args.inflight else (4 if args.config == 3 else (2 if cpus_here >= 6 else 1))
     inflight = max(1, min(inflight, 4))
     from concurrent.futures import ThreadPoolExecutor
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
@@ -263,7 +266,8 @@ def main():
                 # 2 host threads: 5.2k / 6.2k / 6.7k segments/s at 200 / 60 / 25 cycles per bit)
                 fast = args.fano_fast if args.fano_fast else (200 if cpus_here >= 8 else (60 if cpus_here >= 4 else 25))
                 fast_old = L.wspr_set_fano_fast_budget(C.c_uint(fast))
-                workload += "; host Fano budget %d cycles/bit, the rest on the device tail (exact)" % fast
+                workload += ("; Fano attempts on the device (exact wave-parallel search) once the pipeline has seen the "
+                             "band is crowded; before that the host pool with a budget of %d cycles/bit + device tail" % fast)
         else:
             raw, expected = synth_raw_gpu(nseg, 777 + seed, dev, args.snr)
             stride = int(L.wspr_iq_stride())
@@ -308,7 +312,7 @@ def main():
 
         # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
         # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
-        untimed = max(warmup, (4 if config == 2 else 1) * inflight)
+        untimed = max(warmup, {2: 4, 3: 2, 5: 1}[config] * inflight)
         run_steps(untimed)
 
         def timed(n):

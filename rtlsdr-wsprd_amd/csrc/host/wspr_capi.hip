@@ -313,6 +313,10 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
     return wspr::fano_fast_budget().exchange(cycles_per_bit);
 }
 
+int wspr_set_fano_device_mode(int mode) {
+    return wspr::fano_device_setting().exchange(mode < 0 ? -1 : (mode ? 1 : 0));
+}
+
 int wspr_fano_batch_device(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
                            unsigned* metric, unsigned* maxnp, unsigned char* data) {
     try {

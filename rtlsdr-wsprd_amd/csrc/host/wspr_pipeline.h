@@ -17,6 +17,8 @@ namespace wspr {
 // Fano attempts the host pool left unfinished (see Context::decode_resident)
 // cycles/bit the host Fano pool spends before leaving an attempt to the device tail (K6)
 std::atomic<unsigned>& fano_fast_budget();
+// -1 automatic, 0 host pool only, 1 device search for every attempt of a batch (see wspr_pipeline.hip)
+std::atomic<int>& fano_device_setting();
 
 struct PendingFano {
     std::vector<int> seg;                 // owning segment of each attempt
@@ -96,6 +98,8 @@ public:
     int fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
                    unsigned* metric, unsigned* maxnp, unsigned char* data, bool serial_lanes = false,
                    unsigned* steps = nullptr);
+    int fano_resident(const unsigned char* d_symbols, const int* h_offsets, int n, unsigned maxcycles, int* ret,
+                      unsigned* cycles, unsigned char* data);
     int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);
     int decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
                         int* h_nout, DecimState* d_states = nullptr);

@@ -158,6 +158,8 @@ struct Context::Impl {
         nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
     int sub_flip = 0;
+    bool dev_fano = false;           // this batch: Fano attempts on the device (see fano_device_mode())
+    bool crowded = false;            // the previous batch had more than one Fano time-out per ten segments
     int cand_head = 16;              // candidates per segment copied to the host (adapts to the lists seen)
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
@@ -537,6 +539,22 @@ static size_t plan_tables(FineState* items, int n, int* lists, int* n_shared, in
 // spots are exactly the reference's; the re-decode takes the results of the attempts it repeats from
 // a memo (FanoMemo).  WSPR_FANO_FAST / wspr_set_fano_fast_budget() = cycles-per-bit of the fast budget;
 // the default 10000 (the reference's own budget) means no split.
+// Where the Fano attempts of a wave run.  Host (north star, default): the host pool, optionally with the
+// budget split above.  Device: every attempt goes to the wave-parallel device search (K6w) straight from the
+// soft symbols in HBM -- no host Fano at all, nothing postponed, nothing decoded twice; a wave then costs two
+// extra device round trips (~10 ms each when it holds a time-out), which more batches in flight cover.  It is
+// what a rank with two CPUs wants (8 GPUs behind a 16-CPU quota) and what a crowded band wants (thousands of
+// time-outs per batch: 25-27 k segments/s on configs[2] against 21.6 k with the host pool and the budget split);
+// a quiet band decodes faster on the host (configs[1]: 4.4 vs 4.7 ms per step: almost every attempt decodes
+// within microseconds and the device round trips are pure latency).  WSPR_FANO_DEVICE=1 forces it, =0 forbids
+// it, unset = automatic for batches of >= 256 segments per pipeline: when the rank has fewer than four host
+// threads, or when the previous batch of this pipeline ran into more than one time-out per ten segments.
+std::atomic<int>& fano_device_setting() {
+    static std::atomic<int> v{[] { const char* e = getenv("WSPR_FANO_DEVICE"); return e ? atoi(e) : -1; }()};
+    return v;
+}
+static int fano_device_mode() { return fano_device_setting().load(); }
+
 std::atomic<unsigned>& fano_fast_budget() {
     static std::atomic<unsigned> v{[] { const char* e = getenv("WSPR_FANO_FAST"); return e ? (unsigned)atoi(e) : 10000u; }()};
     return v;
@@ -556,7 +574,10 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     const unsigned fast_cfg = fano_fast_budget().load();
     // small batches gain nothing from the split (their time-outs fit the host pool) and would pay
     // the device kernel's latency
-    const unsigned fast = (reload && nseg >= 256) ? std::min(fast_cfg, 10000u) : 0u;
+    const bool dev_fano = fano_device_mode() > 0 ||
+                          (fano_device_mode() < 0 && nseg >= 256 && (host_cpus() < 4 || d->crowded));
+    const unsigned fast = (reload && nseg >= 256 && !dev_fano) ? std::min(fast_cfg, 10000u) : 0u;
+    d->dev_fano = dev_fano;
     std::vector<int> all(nseg);
     for (int s = 0; s < nseg; ++s) all[s] = s;
     PendingFano pend;
@@ -592,6 +613,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     c.t_ms[7] = (double)c.n_fano.load();
     c.t_ms[8] = (double)c.n_timeout.load();
     c.t_ms[9] = (double)c.n_cycles.load();
+    c.crowded = c.n_timeout.load() * 10 > nseg;
     return 0;
 }
 
@@ -847,7 +869,8 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
                                             minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync0, d_sym0,
                                             d_rms0, c.tab, c.stream);
         }
-        HIP_OK(hipMemcpyAsync(h_down, d_blk, down_bytes, hipMemcpyDeviceToHost, c.stream));
+        // device-Fano mode: the soft symbols stay in HBM, only items / sync / rms come down
+        HIP_OK(hipMemcpyAsync(h_down, d_blk, c.dev_fano ? o_sym : down_bytes, hipMemcpyDeviceToHost, c.stream));
         t.stop();
         c.resolve_deferred();
     }
@@ -857,8 +880,36 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
     h_rms = reinterpret_cast<float*>(h_down + o_rms);
     h_sym = reinterpret_cast<unsigned char*>(h_down + o_sym);
 
-    // ---- host: first rung of the jitter ladder ----------------------------
+    // ---- first rung of the jitter ladder -----------------------------------
     const auto t_f0 = std::chrono::steady_clock::now();
+    if (c.dev_fano) {
+        // every gated vector of the wave to the device search, straight from the rung-0 symbols in HBM
+        std::vector<int> att;
+        for (int i = 0; i < nw; ++i) {
+            WaveItem& w = wave[i];
+            w.fine = h_items[i];
+            w.worth = w.fine.sync > minsync1;
+            w.decoded = false;
+            w.jitter = 0;
+            w.rung0_pending = false;
+            if (w.worth && h_sync[i] > minsync2 && h_rms[i] > minrms) att.push_back(i);
+        }
+        const int na = (int)att.size();
+        std::vector<int> ret(na);
+        std::vector<unsigned> cyc(na);
+        std::vector<unsigned char> dat((size_t)na * 10);
+        ctx.fano_resident(d_sym0, att.data(), na, 10000u, ret.data(), cyc.data(), dat.data());
+        for (int k = 0; k < na; ++k) {
+            WaveItem& w = wave[att[k]];
+            w.decoded = ret[k] == 0;
+            w.cycles = cyc[k];
+            memset(w.decdata, 0, sizeof w.decdata);
+            memcpy(w.decdata, dat.data() + (size_t)k * 10, 10);
+            c.n_fano++; c.n_cycles += cyc[k]; if (ret[k]) c.n_timeout++;
+        }
+        c.t_ms[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
+        return;
+    }
     // a candidate that passes the gates but does not decode costs a full time-out here
     // (milliseconds) while a decode costs microseconds: one task per grab, all threads
     Pool& pool0 = (nw >= 256) ? *c.bigpool : *c.pool;
@@ -914,12 +965,46 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             d_sym = reinterpret_cast<unsigned char*>(d_blk + o_sym);
             launch_demod_tiled(wi, wq, samples, d_items, na, d_lists, n_shared, d_lists + na, n_own, 2, kMaxLags, 3,
                                minsync1, d_tabs, d_pw, d_sync, d_sym, d_rms, c.tab, c.stream);
-            HIP_OK(hipMemcpyAsync(h_blk, d_blk, blk, hipMemcpyDeviceToHost, c.stream));
+            HIP_OK(hipMemcpyAsync(h_blk, d_blk, c.dev_fano ? o_sym : blk, hipMemcpyDeviceToHost, c.stream));
             t.stop();
             c.resolve_deferred();
             h_sync = reinterpret_cast<float*>(h_blk);
             h_rms = reinterpret_cast<float*>(h_blk + o_rms);
             h_sym = reinterpret_cast<unsigned char*>(h_blk + o_sym);
+        }
+        if (c.dev_fano) {
+            // every gated (candidate, rung) vector to the device search; the ladder keeps the first success in
+            // rung order, so all are run and the pick is made afterwards (a candidate that decodes on an early
+            // rung wastes its later ones: few do)
+            const auto t_d0 = std::chrono::steady_clock::now();
+            std::vector<int> off, who;
+            for (int a = 0; a < na; ++a)
+                for (int r = 0; r < njit_rest; ++r) {
+                    const int g = a * kMaxLags + (c.jitter_ladder[r + 1] + 63) / 3;
+                    if (h_sync[g] > minsync2 && h_rms[g] > minrms) { off.push_back(g); who.push_back(a * njit_rest + r); }
+                }
+            const int nv = (int)off.size();
+            std::vector<int> ret(nv);
+            std::vector<unsigned> cyc(nv);
+            std::vector<unsigned char> dat((size_t)nv * 10);
+            ctx.fano_resident(d_sym, off.data(), nv, 10000u, ret.data(), cyc.data(), dat.data());
+            std::vector<int> first(na, njit_rest), at(na, -1);
+            for (int k = 0; k < nv; ++k) {
+                const int a = who[k] / njit_rest, r = who[k] % njit_rest;
+                if (r <= first[a]) { c.n_fano++; c.n_cycles += cyc[k]; if (ret[k]) c.n_timeout++; }   // what the serial walk would have run
+                if (ret[k] == 0 && r < first[a]) { first[a] = r; at[a] = k; }
+            }
+            for (int a = 0; a < na; ++a) {
+                if (at[a] < 0) continue;
+                WaveItem& w = wave[again[a]];
+                w.decoded = true;
+                w.jitter = c.jitter_ladder[first[a] + 1];
+                w.cycles = cyc[at[a]];
+                memset(w.decdata, 0, sizeof w.decdata);
+                memcpy(w.decdata, dat.data() + (size_t)at[a] * 10, 10);
+            }
+            c.t_ms[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d0).count();
+            return;
         }
         const auto t_f1 = std::chrono::steady_clock::now();
         // every (candidate, rung) Fano attempt is independent; the ladder keeps the
@@ -1343,6 +1428,39 @@ int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles,
                 memcpy(data + (size_t)i * 10, out11, 10);
             }, 1);
         }
+    }
+    return 0;
+}
+
+// Device Fano search over vectors that are already in HBM: attempt i is the 162 soft symbols at
+// d_symbols + h_offsets[i] * 162 (transmission order).  Results on the host; a vector whose pending-visit
+// store overflowed (-2) is fetched and decoded by the serial host routine.
+int Context::fano_resident(const unsigned char* d_symbols, const int* h_offsets, int n, unsigned maxcycles, int* ret,
+                           unsigned* cycles, unsigned char* data) {
+    Impl& c = *d;
+    if (n <= 0) return 0;
+    int* h_off = static_cast<int*>(c.h_misc.need((size_t)n * 4));
+    memcpy(h_off, h_offsets, (size_t)n * 4);
+    int* doff = static_cast<int*>(c.fz_off.need((size_t)n * 4));
+    int* dret = static_cast<int*>(c.fz_ret.need((size_t)n * 4));
+    unsigned* dcyc = static_cast<unsigned*>(c.fz_cyc.need((size_t)n * 4));
+    unsigned char* ddat = static_cast<unsigned char*>(c.fz_dat.need((size_t)n * 10));
+    upload(doff, h_off, (size_t)n * 4, c.stream);
+    launch_fano_wave(d_symbols, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, nullptr, nullptr, ddat, nullptr,
+                     static_cast<uint32_t*>(c.fz_pool.need(fano_wave_scratch_words(n) * 4)), c.stream);
+    HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
+    sync();
+    const FanoMetrics& met = default_metrics();
+    for (int i = 0; i < n; ++i) {
+        if (ret[i] != -2) continue;
+        unsigned char sym[kNSymD], out11[11] = {0};
+        HIP_OK(hipMemcpy(sym, d_symbols + (size_t)h_offsets[i] * kNSymD, kNSymD, hipMemcpyDeviceToHost));
+        deinterleave162(sym);
+        unsigned metric, maxnp;
+        ret[i] = fano_decode(&metric, &cycles[i], &maxnp, out11, sym, kNBits, met.tab, 60, maxcycles);
+        memcpy(data + (size_t)i * 10, out11, 10);
     }
     return 0;
 }

@@ -20,6 +20,7 @@
 #include "wspr_device.h"
 #include "fano_wave.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace wspr {
 namespace {
@@ -56,7 +57,7 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
                       const short* __restrict__ metric0, unsigned maxcycles,
                       int* __restrict__ ret, unsigned* __restrict__ cycles, unsigned* __restrict__ metric,
                       unsigned* __restrict__ maxnp, unsigned char* __restrict__ data, unsigned* __restrict__ steps_out,
-                      uint32_t* __restrict__ gpool) {
+                      uint32_t* __restrict__ gpool, int* __restrict__ next_vector) {
     __shared__ uint32_t lpool[kGlobal ? 1 : 5 * kCap];
     uint32_t* __restrict__ gp = kGlobal ? gpool + (size_t)blockIdx.x * 5 * kCap : nullptr;
     auto ld = [&](int arr, int i) -> uint32_t { if constexpr (kGlobal) return gp[arr * kCap + i]; else return lpool[arr * kCap + i]; };
@@ -65,11 +66,23 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
     __shared__ unsigned char symd[kNSymD];
     __shared__ short mt[256];
     const int lane = threadIdx.x;
-    const int v = blockIdx.x;
+    for (int e = lane; e < 256; e += 64) mt[e] = metric0[e];
+    // persistent grid: a wave takes the next unclaimed vector until none is left (the grid -- and with it the
+    // device memory for the pending-visit stores -- is bounded whatever the number of vectors; quick decodes
+    // and full time-outs balance themselves)
+    for (;;) {
+    int v;
+    if (next_vector) {
+        int got = 0;
+        if (lane == 0) got = atomicAdd(next_vector, 1);
+        v = __builtin_amdgcn_readfirstlane(got);
+    } else {
+        v = blockIdx.x;
+    }
     if (v >= n) return;
+    __syncthreads();                                        // the previous vector's LDS tables are no longer read
 
     // ---- branch metrics of the 81 nodes (fano.c:118-124), de-interleaving on the fly ------------
-    for (int e = lane; e < 256; e += 64) mt[e] = metric0[e];
     {
         const unsigned char* __restrict__ sym = symbols + (size_t)offsets[v] * kNSymD;
         int base = 0;
@@ -203,27 +216,35 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         for (int k = 0; k < 10; ++k) data[(size_t)v * 10 + k] = d[k];
         if (steps_out) steps_out[v] = steps;
     }
+    if (!next_vector) return;
+    }
 }
 
 }  // namespace
 
+constexpr int kWaveGrid = 8192;                              // 256 CUs x 32 waves
+
 size_t fano_wave_scratch_words(int n) {                     // device scratch for the global-store form
-    return (size_t)n * 5 * 4096;
+    return (size_t)std::min(n, kWaveGrid) * 5 * 4096 + 16;   // + the work counter
 }
 
 void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, const short* metric0,
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
                       unsigned char* data, unsigned* steps, uint32_t* scratch, hipStream_t st) {
     if (n <= 0) return;
-    // WSPR_FANO_WAVE_STORE=lds: the 1024-visit store in LDS (7 waves per CU); default: 4096 visits per wave in
-    // device memory (scratch = fano_wave_scratch_words(n) words)
+    // WSPR_FANO_WAVE_STORE=lds: the 1024-visit store in LDS (7 waves per CU, one workgroup per vector); default:
+    // 4096 visits per wave in device memory (scratch = fano_wave_scratch_words(n) words) and a persistent grid
     static const bool lds = [] { const char* e = getenv("WSPR_FANO_WAVE_STORE"); return e && e[0] == 'l'; }();
-    if (lds || !scratch)
+    if (lds || !scratch) {
         hipLaunchKernelGGL((fano_wave_kernel<1024, false>), dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
-                           ret, cycles, metric, maxnp, data, steps, (uint32_t*)nullptr);
-    else
-        hipLaunchKernelGGL((fano_wave_kernel<4096, true>), dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
-                           ret, cycles, metric, maxnp, data, steps, scratch);
+                           ret, cycles, metric, maxnp, data, steps, (uint32_t*)nullptr, (int*)nullptr);
+        return;
+    }
+    const int grid = std::min(n, kWaveGrid);
+    int* counter = reinterpret_cast<int*>(scratch + (size_t)grid * 5 * 4096);
+    (void)hipMemsetAsync(counter, 0, sizeof(int), st);
+    hipLaunchKernelGGL((fano_wave_kernel<4096, true>), dim3(grid), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
+                       ret, cycles, metric, maxnp, data, steps, scratch, counter);
 }
 
 }  // namespace wspr

@@ -70,15 +70,24 @@ def test_config3_8192_segments_x_10_signals(env):
         ref, _, _ = ol.decode(I[s].cpu().numpy(), Q[s].cpu().numpy(), NS)
         assert _same_as_oracle(dec.spots(s), ref), s
         assert len(ref) >= 8
-    # the Fano budget split (what bench.py runs this config with) never changes a result
+    # neither the Fano budget split of the host pool nor the device search for every attempt (what such a
+    # crowded batch runs by default once a pipeline has seen its time-outs) ever changes a result
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
     old = L.wspr_set_fano_fast_budget(C.c_uint(300))
+    old_mode = L.wspr_set_fano_device_mode(0)
     try:
         dec.decode(I, Q)
+        assert [[_tup(x) for x in dec.spots(s)] for s in range(nseg)] == full
+        assert w.last_timings()["fano_left_to_device"] > 1000
+        L.wspr_set_fano_device_mode(1)
+        dec.decode(I, Q)
+        assert [[_tup(x) for x in dec.spots(s)] for s in range(nseg)] == full
+        tm = w.last_timings()
+        assert tm["host_fano_ms"] == 0 and tm["segments_redecoded"] == 0 and tm["fano_timeouts"] > 1000
     finally:
         L.wspr_set_fano_fast_budget(C.c_uint(old))
-    assert [[_tup(x) for x in dec.spots(s)] for s in range(nseg)] == full
+        L.wspr_set_fano_device_mode(old_mode)
 
 
 # ------------------------------------------------------------------ configs[4]

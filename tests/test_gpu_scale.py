@@ -71,6 +71,7 @@ def test_fano_budget_split_never_changes_results(env):
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
     old = L.wspr_set_fano_fast_budget(C.c_uint(10000))  # split disabled: the exact schedule
+    old_mode = L.wspr_set_fano_device_mode(0)           # host pool (this test is about its budget split)
     try:
         dec = w.BatchDecoder(nseg, 16)
         dec.decode(I, Q)
@@ -86,8 +87,15 @@ def test_fano_budget_split_never_changes_results(env):
             assert got == exact, budget
             if budget == 3:
                 assert tm["fano_left_to_device"] > 100 and tm["segments_redecoded"] > 20
+        # every attempt on the device instead (what crowded batches run by default): same spots, no host Fano
+        L.wspr_set_fano_device_mode(1)
+        dec.decode(I, Q)
+        got = [[_tup(x) for x in dec.spots(s)] for s in range(nseg)]
+        tm = w.last_timings()
+        assert got == exact and tm["fano_left_to_device"] == 0 and tm["segments_redecoded"] == 0 and tm["host_fano_ms"] == 0
     finally:
         L.wspr_set_fano_fast_budget(C.c_uint(old))
+        L.wspr_set_fano_device_mode(old_mode)
     assert sum(len(x) for x in exact) > nseg             # the workload really decodes
     # at these SNRs the decoder itself yields the odd false decode (the oracle yields the same ones)
     assert sum(m[0].decode() not in expected[s] for s in range(nseg) for m in exact[s]) <= 0.01 * sum(len(x) for x in exact)
@@ -223,6 +231,7 @@ def test_two_lanes_with_fano_split_and_memo(env):
     L.wspr_set_fano_fast_budget.restype = C.c_uint
     batches = [bench.synth_batch_gpu(nseg, 300 + k, dev, 4, -22.0, -30.0, 0.3)[:2] for k in range(2)]
     old = L.wspr_set_fano_fast_budget(C.c_uint(10000))
+    old_mode = L.wspr_set_fano_device_mode(0)
     try:
         exact = []
         for I, Q in batches:
@@ -244,6 +253,7 @@ def test_two_lanes_with_fano_split_and_memo(env):
             out = [f.result() for f in [ex.submit(worker, k) for k in range(2)]]
     finally:
         L.wspr_set_fano_fast_budget(C.c_uint(old))
+        L.wspr_set_fano_device_mode(old_mode)
     for k in range(2):
         for spots, tm in out[k]:
             assert spots == exact[k], k
