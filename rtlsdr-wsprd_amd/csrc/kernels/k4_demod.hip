@@ -360,6 +360,150 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     pw_out[((size_t)item * nlag + m) * kNSymD + i0 + il] = acc.amplitudes();
 }
 
+// -----------------------------------------------------------------------------
+// Lag scan (mode 0: 33 lags, step 8) of a DRIFTING candidate.
+//
+// A drifting candidate has one phasor table per symbol, so the table operand differs between the symbols a
+// wave holds and cannot come from scalar registers.  With one lag per lane (demod_tile_kernel<8, false>) the
+// two 16-byte table reads per lane and step make the kernel LDS-return-bound (20 LDS clocks per wave step,
+// four waves per LDS, against 16 packed VALU instructions = 64 clocks).  Here a lane runs THREE lags of one
+// symbol (lane = (symbol, g), lags g, g+11, g+22): the table entry is read once per step and serves three
+// 16-instruction accumulator updates, so the kernel is VALU-bound again.
+//   * workgroup = ONE wave = 5 symbols x 11 lanes (55 of 64 lanes); 33 workgroups per candidate.
+//   * the tables are not staged whole (8 KB per symbol): lanes 0..19 carry the 5 x 4 phasor recurrences
+//     (wsprd.c:158-188) in registers and emit them 32 steps at a time into a 5 KB LDS ring; the workgroup's
+//     LDS is 22 KB, so seven waves share a CU.
+//   * samples: one tile for the 5 symbols, transposed by the lag step (lanes of a symbol read consecutive
+//     8-byte words) and skewed by 11 words per 256 samples, so that the three symbols of a half wave fall on
+//     different banks (symbol stride 32 + 11 = 43 = 11 mod 32 words).
+// Same operations per accumulator as demod_kernel => identical bits.
+constexpr int kDrSyms = 5;
+constexpr int kDrGroups = 11;                       // lanes per symbol; 3 lags each
+constexpr int kDrChunk = 32;                        // table steps per ring fill
+constexpr int kDrSpan = kSps * kDrSyms + 8 * 32;    // samples the 5 symbols x 33 lags touch: 1536
+constexpr int kDrSkew = 11;
+constexpr int kDrPitch = kDrSpan / 8 + kDrSkew * (kDrSpan / 256) + 1;      // 8-byte words per tile row
+constexpr int kDrTabStride = 2 * kDrChunk + 2;      // float4 words per symbol in the ring (+32 B: bank offset 8 per symbol)
+
+__device__ __forceinline__ int drift_tile_word(int e) { return (e & 7) * kDrPitch + (e >> 3) + kDrSkew * (e >> 8); }
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3)))
+void demod_drift_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                        const FineState* __restrict__ items, const int* __restrict__ item_list,
+                        float4* __restrict__ pw_out) {
+    __shared__ float2 tile[8 * kDrPitch];
+    __shared__ float4 tab[kDrSyms * kDrTabStride];
+    constexpr int nlag = 3 * kDrGroups;
+    const int item = item_list[blockIdx.y];
+    const FineState st = items[item];
+    const int i0 = blockIdx.x * kDrSyms, lane = threadIdx.x;
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int kbase = st.shift_coarse - 128 + kSps * i0;
+#pragma unroll
+    for (int e0 = 0; e0 < kDrSpan; e0 += 64 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 64 * u + lane, k = kbase + e;
+            const bool ok = (k > 0) && (k < np);             // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
+            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tile[drift_tile_word(e0 + 64 * u + lane)] = v[u];
+    }
+    // table lanes: (symbol, tone) recurrences, seeds as in phasor_table_kernel
+    const int bil = lane >> 2, tone = lane & 3;
+    const bool builder = lane < kDrSyms * 4;
+    float cd = 1.0f, sd = 0.0f, pc = 1.0f, ps = 0.0f;
+    if (builder) {
+        const int sym = i0 + bil;
+        const float fp = (float)((double)st.freq_coarse + ((double)st.drift / 2.0) * (double)((float)sym - 81.0f) / (double)81.0f);
+        const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
+        const float dphi = (float)(kTwoPiDt * ((double)fp + off));
+        cd = glibc_cosf(dphi);
+        sd = glibc_sinf(dphi);
+    }
+    float* __restrict__ tabw = reinterpret_cast<float*>(tab + bil * kDrTabStride) + tone;
+
+    const int il = lane / kDrGroups, g = lane - il * kDrGroups;
+    const bool working = (lane < kDrSyms * kDrGroups) && (i0 + il < kNSymD);
+    const float4* __restrict__ tb = tab + (working ? il : 0) * kDrTabStride;
+    const int e_lane = 8 * g + kSps * (working ? il : 0);
+    ToneAcc acc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r].clear();
+    for (int ch = 0; ch < kSps / kDrChunk; ++ch) {
+        __syncthreads();                                     // the previous 32 table steps have been consumed
+        if (builder) {
+            for (int jj = 0; jj < kDrChunk; ++jj) {
+                if (ch + jj > 0) {
+                    const float a = pc * cd, b = ps * sd, e = pc * sd, d = ps * cd;
+                    pc = a - b;
+                    ps = e + d;
+                }
+                tabw[8 * jj] = pc;
+                tabw[8 * jj + 4] = ps;
+            }
+        }
+        __syncthreads();
+        if (working) {
+#pragma unroll 1
+            for (int jb = 0; jb < kDrChunk; jb += 8) {
+                const float2* __restrict__ t0[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int e = e_lane + 8 * kDrGroups * r + kDrChunk * ch + jb;      // a multiple of 8
+                    t0[r] = tile + (e >> 3) + kDrSkew * (e >> 8);
+                }
+                // operands of step u+1 are in flight while step u is consumed; the 24 products of a step are
+                // formed before the 24 accumulator updates, so dependent instructions sit far apart
+                float4 c4 = tb[2 * jb], s4 = tb[2 * jb + 1];
+                float2 d[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) d[r] = t0[r][0];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float4 cn = c4, sn = s4;
+                    float2 dn[3] = {d[0], d[1], d[2]};
+                    if (u + 1 < 8) {
+                        cn = tb[2 * (jb + u + 1)];
+                        sn = tb[2 * (jb + u + 1) + 1];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) dn[r] = t0[r][(u + 1) * kDrPitch];
+                    }
+                    const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+                    v2f p[3][8];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const v2f xx = {d[r].x, d[r].x}, yy = {d[r].y, d[r].y};
+                        p[r][0] = xx * c01; p[r][1] = xx * c23; p[r][2] = xx * s01; p[r][3] = xx * s23;
+                        p[r][4] = yy * s01; p[r][5] = yy * s23; p[r][6] = yy * c01; p[r][7] = yy * c23;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {           // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
+                        acc[r].i01 = acc[r].i01 + p[r][0]; acc[r].i23 = acc[r].i23 + p[r][1];
+                        acc[r].q01 = acc[r].q01 - p[r][2]; acc[r].q23 = acc[r].q23 - p[r][3];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        acc[r].i01 = acc[r].i01 + p[r][4]; acc[r].i23 = acc[r].i23 + p[r][5];
+                        acc[r].q01 = acc[r].q01 + p[r][6]; acc[r].q23 = acc[r].q23 + p[r][7];
+                    }
+                    c4 = cn; s4 = sn;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) d[r] = dn[r];
+                }
+            }
+        }
+    }
+    if (working) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            pw_out[((size_t)item * nlag + g + kDrGroups * r) * kNSymD + i0 + il] = acc[r].amplitudes();
+    }
+}
+
 // folds the 162 per-symbol tone amplitudes of one (candidate, lag) in symbol order
 __global__ __launch_bounds__(64)
 void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restrict__ items, int nitems,
@@ -496,6 +640,74 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
             for (int jj = 0; jj < kFsChunk; ++jj) {
                 const int j = kFsChunk * c + jj;
                 acc.step(tile[sym][jj], tb[2 * j], tb[2 * j + 1]);
+            }
+        }
+    }
+    if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
+}
+
+// The same scan for a DRIFTING candidate: every (hypothesis, symbol) has its own four tone phasors and each
+// of them is used by exactly one lane, so there is nothing to share and no table: a lane carries the four
+// recurrences (wsprd.c:158-188) in registers next to its accumulators, 12 + 16 packed instructions per sample.
+// Staging, thread mapping and output layout are those of freq_tile_kernel, so freq_metric_kernel picks the
+// winner and forms the first rung's soft symbols for drifting candidates too (the general kernel ran the five
+// hypotheses as five workgroups and the first rung as a sixth pass over the samples).
+__global__ __launch_bounds__(kFsThreads)
+void freq_drift_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                       const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin, float fstep,
+                       float4* __restrict__ pw_out) {
+    __shared__ float2 tile[kNSymD][kFsChunk + 1];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const FineState st = items[item_list[slot]];
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int f = tid / kNSymD, sym = tid - f * kNSymD;
+    const bool working = f < kNFreq;
+
+    float2 nxt[kFsPerThread];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < kFsPerThread; ++u) {
+            const int e = u * kFsThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
+            const int k = st.shift + kSps * row + kFsChunk * c + col;
+            const bool ok = (e < kNSymD * kFsChunk) && (k > 0) && (k < np);
+            nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+    };
+    fetch(0);
+    v2f cd01 = {1.0f, 1.0f}, cd23 = cd01, sd01 = {0.0f, 0.0f}, sd23 = sd01;
+    if (working) {
+        const float f0 = st.freq + (float)(ifmin + f) * fstep;          // *freq + ifreq * fstep, wsprd.c:151
+        const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)((float)sym - 81.0f) / (double)81.0f);
+        const double fpd = (double)fp;
+        float sn, cs;
+        glibc_sincosf_pair((float)(kTwoPiDt * (fpd - kDf15)), &sn, &cs); cd01.x = cs; sd01.x = sn;
+        glibc_sincosf_pair((float)(kTwoPiDt * (fpd - kDf05)), &sn, &cs); cd01.y = cs; sd01.y = sn;
+        glibc_sincosf_pair((float)(kTwoPiDt * (fpd + kDf05)), &sn, &cs); cd23.x = cs; sd23.x = sn;
+        glibc_sincosf_pair((float)(kTwoPiDt * (fpd + kDf15)), &sn, &cs); cd23.y = cs; sd23.y = sn;
+    }
+    v2f c01 = {1.0f, 1.0f}, c23 = c01, s01 = {0.0f, 0.0f}, s23 = s01;
+    ToneAcc acc;
+    acc.clear();
+    for (int c = 0; c < kSps / kFsChunk; ++c) {
+        __syncthreads();                                             // the previous chunk has been consumed
+#pragma unroll
+        for (int u = 0; u < kFsPerThread; ++u) {
+            const int e = u * kFsThreads + tid;
+            if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
+        }
+        __syncthreads();
+        if (c + 1 < kSps / kFsChunk) fetch(c + 1);
+        if (working) {
+#pragma unroll 8
+            for (int jj = 0; jj < kFsChunk; ++jj) {
+                if (c + jj > 0) {
+                    const v2f a01 = c01 * cd01, b01 = s01 * sd01, e01 = c01 * sd01, d01 = s01 * cd01;
+                    const v2f a23 = c23 * cd23, b23 = s23 * sd23, e23 = c23 * sd23, d23 = s23 * cd23;
+                    c01 = a01 - b01; s01 = e01 + d01;
+                    c23 = a23 - b23; s23 = e23 + d23;
+                }
+                acc.step(tile[sym][jj], make_float4(c01.x, c01.y, c23.x, c23.y), make_float4(s01.x, s01.y, s23.x, s23.y));
             }
         }
     }
@@ -654,6 +866,16 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                            sync_out, sym_out, rms_out, t.sync);
     }
     if (n_own > 0) {
+        static const bool general = [] { const char* e = getenv("WSPR_K4_DRIFT"); return e && e[0] == 't'; }();
+        if (!general) {
+            // pw rows of the drifting candidates follow those of the drift-free ones
+            float4* pw_own = reinterpret_cast<float4*>(pw) + (size_t)n_shared * kNFreq * kNSymD;
+            hipLaunchKernelGGL(freq_drift_kernel, dim3(n_own), dim3(kFsThreads), 0, st, dI, dQ, samples, items, list_own,
+                               -2, 0.1f, pw_own);
+            hipLaunchKernelGGL(freq_metric_kernel, dim3(n_own), dim3(64), 0, st, pw_own, items, list_own, n_own, -2, 0.1f,
+                               minsync1, sync_out, sym_out, rms_out, t.sync);
+            return;
+        }
         // scratch_sync is indexed [item][5] by the general kernel
         hipLaunchKernelGGL(demod_kernel, dim3(kNFreq, n_own), dim3(192), 0, st, dI, dQ, samples, items, list_own, 1,
                            kNFreq, lagstep, -2, 0.1f, (const int*)nullptr, 0.0f, scratch_sync, (unsigned char*)nullptr,
@@ -685,13 +907,18 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
     static const int scalar_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return (e && e[0] == 'l') ? 0 : 1; }();
+    // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
+    static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0)                                                                                        \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
                                threads(kTileSymsShared), 8192 + tile_bytes(kTileSymsShared), st, dI, dQ, samples, \
                                items, list_shared, mode, nlag, minsync1, tabs, pw4, scalar_tab);                 \
-        if (n_own > 0)                                                                                           \
+        if (n_own > 0 && STEP == 8 && nlag == 33 && mode == 0 && drift_kernel)                                   \
+            hipLaunchKernelGGL(demod_drift_kernel, dim3((kNSymD + kDrSyms - 1) / kDrSyms, n_own), dim3(64), 0, st, \
+                               dI, dQ, samples, items, list_own, pw4);                                           \
+        else if (n_own > 0)                                                                                      \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSymsOwn, n_own),             \
                                threads(kTileSymsOwn), kTileSymsOwn * kOwnTabPitch * 16 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
                                samples, items, list_own, mode, nlag, minsync1, tabs, pw4, 0);                    \
