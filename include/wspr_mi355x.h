@@ -258,6 +258,10 @@ int wspr_set_fano_device_mode(int mode);
  * ms[0] = average milliseconds per launch. */
 int wspr_bench_decimate(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_idat, void *d_qdat,
                         int iters, double *ms);
+/* Read-bandwidth calibration for that roofline: `iters` launches of a kernel with K0's access pattern
+ * (one workgroup per pair of CIC blocks, 16-byte non-temporal loads) and no arithmetic; ms[0] = average
+ * milliseconds per launch over the same resident raw rows. */
+int wspr_calib_read(const void *d_raw, size_t bytes_per_seg, int nseg, int iters, double *ms);
 /* PMC calibration: `iters` launches of a 4-byte-per-lane stream copy of nfloats floats on the
  * library's stream (known traffic: 4*nfloats bytes read and written per launch). */
 int wspr_calib_copy(const void *d_src, void *d_dst, size_t nfloats, int iters);

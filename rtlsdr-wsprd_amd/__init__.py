@@ -95,6 +95,7 @@ def lib():
         L.wspr_decimate_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.wspr_decimate_u8_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.wspr_bench_decimate.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.wspr_calib_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.wspr_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.nhash.restype = C.c_uint32
         L.nhash.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]

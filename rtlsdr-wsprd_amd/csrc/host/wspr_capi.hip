@@ -338,6 +338,12 @@ int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void*
     } catch (const std::exception& e) { return fail("wspr_bench_decimate", e); }
 }
 
+int wspr_calib_read(const void* d_raw, size_t bytes_per_seg, int nseg, int iters, double* ms) {
+    try {
+        return Context::get().bench_decimate(d_raw, bytes_per_seg, nseg, nullptr, nullptr, iters, ms);
+    } catch (const std::exception& e) { return fail("wspr_calib_read", e); }
+}
+
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {
     try {

@@ -1370,6 +1370,10 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, c.stream));
     for (int it = 0; it < iters; ++it) {
+        if (!dI) {                                            // read calibration: K0's access pattern, no arithmetic
+            launch_calib_read(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, reinterpret_cast<unsigned*>(d_nv), c.stream);
+            continue;
+        }
         launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream);
         launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
     }

@@ -180,6 +180,130 @@ void cic_block_sums_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg
     }
 }
 
+// ---- whole segments (no carried state): one WAVE per block ------------------------------------------------
+// The general kernel above routes every vector through block-edge tests (64-bit), A/B accumulator masks and
+// an inline per-sample path that a whole wave executes whenever one of its lanes holds an edge vector: ~55
+// instructions per 16 bytes plus ~250 per edge, 0.53 of HBM peak where a kernel that only reads the same rows
+// in the same pattern reaches 0.88 (wspr_calib_read).  Without a carried state the geometry is fixed, so:
+//   * a wave owns one block: 799 or 800 interior vectors + at most two edge vectors, four accumulators, no
+//     routing; the reduction is one wave sum, no LDS, no barrier;
+//   * three rounds of 4 x 64 interior vectors run with no bounds test at all (768 <= 799);
+//   * ONE masked round takes the remaining <= 32 interior vectors and the two edge vectors (lanes 62, 63):
+//     bytes outside the block are cleared after the sign flip (x = 0 contributes nothing), the weight base
+//     R + lo - 8v covers a vector that starts before the block;
+//   * raw bytes 0x00 (-128, whose int8 negation wraps) are only detected in the hot loop
+//     (two instructions per dword); a wave that saw one redoes its block sample by sample afterwards.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+template <bool kMasked>
+__device__ __forceinline__ void block_sum_vector(const u4 q, const int wbase, const int k_lo, const int k_hi,
+                                                 unsigned (&acc)[4], unsigned (&zacc)[4]) {
+    // has-zero-byte test, one subtract and one three-input bit operation per dword
+    zacc[0] |= (q.x - 0x01010101u) & ~q.x;
+    zacc[1] |= (q.y - 0x01010101u) & ~q.y;
+    zacc[2] |= (q.z - 0x01010101u) & ~q.z;
+    zacc[3] |= (q.w - 0x01010101u) & ~q.w;
+    int w[4] = {(int)(q.x ^ 0x80808080u), (int)(q.y ^ 0x80808080u), (int)(q.z ^ 0x80808080u), (int)(q.w ^ 0x80808080u)};
+    if (kMasked) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned m0 = (2 * d >= k_lo && 2 * d < k_hi) ? 0x0000ffffu : 0u;
+            const unsigned m1 = (2 * d + 1 >= k_lo && 2 * d + 1 < k_hi) ? 0xffff0000u : 0u;
+            w[d] &= (int)(m0 | m1);
+        }
+    }
+    // sample k of the vector has mixer phase k & 3 (a vector starts at a multiple of 8): xi, xq as signed
+    // 4 x int8 dot products with constant weights, see cic_block_sums_kernel; nu = -sum_k k x_k
+    int tI = __builtin_amdgcn_sdot4(w[0], (int)0xff000001u, 0, false);
+    tI = __builtin_amdgcn_sdot4(w[1], (int)0x010000ffu, tI, false);
+    tI = __builtin_amdgcn_sdot4(w[2], (int)0xff000001u, tI, false);
+    tI = __builtin_amdgcn_sdot4(w[3], (int)0x010000ffu, tI, false);
+    int tQ = __builtin_amdgcn_sdot4(w[0], (int)0x00010100u, 0, false);
+    tQ = __builtin_amdgcn_sdot4(w[1], (int)0x00ffff00u, tQ, false);
+    tQ = __builtin_amdgcn_sdot4(w[2], (int)0x00010100u, tQ, false);
+    tQ = __builtin_amdgcn_sdot4(w[3], (int)0x00ffff00u, tQ, false);
+    // W += sum_k (R - (8v + k - lo)) x_k = wbase * t - sum_k k x_k; the second term is accumulated by the dot
+    // products themselves (wrap-around int32 sums are associative)
+    int nuI = __builtin_amdgcn_sdot4(w[0], (int)0x01000000u, (int)acc[2], false);
+    nuI = __builtin_amdgcn_sdot4(w[1], (int)0xfd000002u, nuI, false);
+    nuI = __builtin_amdgcn_sdot4(w[2], (int)0x050000fcu, nuI, false);
+    nuI = __builtin_amdgcn_sdot4(w[3], (int)0xf9000006u, nuI, false);
+    int nuQ = __builtin_amdgcn_sdot4(w[0], (int)0x00ff0000u, (int)acc[3], false);
+    nuQ = __builtin_amdgcn_sdot4(w[1], (int)0x00030200u, nuQ, false);
+    nuQ = __builtin_amdgcn_sdot4(w[2], (int)0x00fbfc00u, nuQ, false);
+    nuQ = __builtin_amdgcn_sdot4(w[3], (int)0x00070600u, nuQ, false);
+    acc[0] += (unsigned)tI;
+    acc[1] += (unsigned)tQ;
+    acc[2] = (unsigned)nuI + (unsigned)__mul24(wbase, tI);
+    acc[3] = (unsigned)nuQ + (unsigned)__mul24(wbase, tQ);
+}
+
+// per-sample path of one vector, samples n in [lo, hi) only (the reference's arithmetic, sample by sample)
+__device__ __noinline__ void block_sum_vector_exact(const u4 q, const int n0, const int lo, const int hi,
+                                                    unsigned (&acc)[4]) {
+    const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int n = n0 + k;
+        const unsigned wv = wds[k >> 1] >> (16 * (k & 1));
+        const int a = s8(wv), b = s8(wv >> 8);
+        int xi, xq;
+        switch (k & 3) {                                          // (1, j, -1, -j)[n & 3], n = 8v + k
+            case 0:  xi = a;        xq = b;        break;
+            case 1:  xi = neg8(b);  xq = a;        break;
+            case 2:  xi = neg8(a);  xq = neg8(b);  break;
+            default: xi = b;        xq = neg8(a);  break;
+        }
+        const unsigned m = (n >= lo && n < hi) ? 1u : 0u;
+        const unsigned wgt = (unsigned)(kR - (n - lo));
+        acc[0] += m * (unsigned)xi;        acc[1] += m * (unsigned)xq;
+        acc[2] += m * wgt * (unsigned)xi;  acc[3] += m * wgt * (unsigned)xq;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void cic_block_sums_fast_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks,
+                                int32_t* __restrict__ sums) {
+    const int seg = blockIdx.y, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblocks) return;                                     // wave-uniform
+    const int lo = b * kR, hi = lo + kR;                          // the block's samples
+    const int vi_lo = (lo + 7) >> 3, vi_hi = hi >> 3;             // its interior vectors [vi_lo, vi_hi)
+    const int v_max = (int)((bytes_per_seg / 2 + 7) >> 3);        // vectors in a row
+    const u4* __restrict__ vec = reinterpret_cast<const u4*>(raw + (size_t)seg * bytes_per_seg);
+    unsigned acc[4] = {0u, 0u, 0u, 0u}, zacc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+        const int v0 = vi_lo + 256 * r + lane;
+        u4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = __builtin_nontemporal_load(vec + v0 + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) block_sum_vector<false>(q[u], kR + lo - 8 * (v0 + 64 * u), 0, 8, acc, zacc);
+    }
+    {   // the rest of the interior and the two edge vectors
+        int v = vi_lo + 768 + lane, k_lo = 0, k_hi = (v < vi_hi) ? 8 : 0;
+        if (lane == 62) { v = vi_lo - 1; k_lo = lo - 8 * v; k_hi = (k_lo < 8) ? 8 : 0; }     // k_lo == 8: the block starts on a vector
+        if (lane == 63) { v = vi_hi; k_hi = hi - 8 * v; }                                    // 0: it ends on one
+        const int vl = min(max(v, 0), v_max - 1);
+        const u4 q = __builtin_nontemporal_load(vec + vl);
+        block_sum_vector<true>(q, kR + lo - 8 * v, k_lo, k_hi, acc, zacc);
+    }
+    if (__any(((zacc[0] | zacc[1] | zacc[2] | zacc[3]) & 0x80808080u) != 0u)) {                      // clipping at the negative rail: exact path
+        acc[0] = acc[1] = acc[2] = acc[3] = 0u;
+        for (int v = vi_lo - 1 + lane; v <= vi_hi; v += 64) {
+            if (v < 0 || v >= v_max) continue;
+            const u4 q = __builtin_nontemporal_load(vec + v);
+            block_sum_vector_exact(q, 8 * v, lo, hi, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = wave_sum(acc[i]);
+        if (lane == 0) sums[((size_t)seg * nblocks + b) * 4 + i] = (int32_t)s;
+    }
+}
+
 // Integrators at the decimation instants by parallel prefix sums (exact: arithmetic mod 2^32 is
 // associative).  With P1 = inclusive scan of S:  I1(b) = P1[b],  I2(b) = scan_b( R*P1[b-1] + W_b ).
 // One workgroup per (segment, rail); thread t owns a contiguous chunk of blocks.
@@ -315,12 +439,51 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     if (nblocks <= 0) return;
     int32_t* sums = scratch;
     uint32_t* x2 = reinterpret_cast<uint32_t*>(scratch + (size_t)nseg * nblocks * 4);
-    hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
-                       bytes_per_seg, nblocks, sums, states);
+    // whole segments take the wave-per-block kernel (sample indices fit 31 bits: rows below 4 GiB);
+    // WSPR_K0_KERNEL=general keeps them on the kernel that also serves carried states
+    static const bool general = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'g'; }();
+    if (!states && !general && bytes_per_seg < ((size_t)1 << 32))
+        hipLaunchKernelGGL(cic_block_sums_fast_kernel, dim3((nblocks + 3) / 4, nseg), dim3(256), 0, st, raw,
+                           bytes_per_seg, nblocks, sums);
+    else
+        hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
+                           bytes_per_seg, nblocks, sums, states);
     hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg, 2), dim3(kScanThreads), 0, st, sums, nblocks, nsamp, x2, states);
     hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, x2, nblocks, nsamp,
                        dI, dQ, n_out, states);
     if (states) hipLaunchKernelGGL(cic_carry_kernel, dim3(nseg), dim3(128), 0, st, x2, nblocks, nsamp, states);
+}
+
+// Calibration for K0's roofline: the same read pattern as cic_block_sums_kernel (one workgroup per 12 802
+// bytes of a row, aligned 16-byte non-temporal loads, four in flight per lane) with one add per dword instead
+// of the mixer and block-sum arithmetic -- what the memory system delivers to a read-only stream of this shape.
+namespace {
+__global__ __launch_bounds__(256)
+void calib_read_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks, unsigned* __restrict__ out) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4* __restrict__ vec = reinterpret_cast<const u4*>(raw + (size_t)blockIdx.y * bytes_per_seg);
+    const long first = (long)blockIdx.x * 2 * kR, last = min(first + 2 * kR, (long)(bytes_per_seg / 2));
+    const long v_lo = first >> 3, v_end = (last + 7) >> 3;
+    unsigned acc = 0;
+    for (long v0 = v_lo + threadIdx.x; v0 < v_end; v0 += 4 * 256) {
+        u4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long v = v0 + 256 * u;
+            q[u] = __builtin_nontemporal_load(vec + ((v < v_end) ? v : v_lo));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += q[u].x + q[u].y + q[u].z + q[u].w;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc == 0x9e3779b9u) out[0] = acc;      // keeps the loads alive; practically never true
+    (void)nblocks;
+}
+}  // namespace
+void launch_calib_read(const uint8_t* raw, size_t bytes_per_seg, int nseg, unsigned* out, hipStream_t st) {
+    const int nblocks = decimate_blocks(bytes_per_seg / 2, false);
+    if (nseg <= 0 || nblocks <= 0) return;
+    hipLaunchKernelGGL(calib_read_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw, bytes_per_seg, nblocks, out);
 }
 
 }  // namespace wspr

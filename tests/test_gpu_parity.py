@@ -318,6 +318,45 @@ def test_decimator_bit_exact_vs_oracle(w):
     assert np.array_equal(gi, oi) and np.array_equal(gq, oq)
 
 
+def test_decimator_block_edges_and_clipping_equal_oracle(w):
+    """The whole-segment front end gives a wave one CIC block: interior vectors take the dot-product path, the
+    two vectors that straddle the block's edges a masked one, and a block that holds a raw 0x00 byte (int8 -128,
+    whose negation wraps) is redone sample by sample.  Zero bytes are planted on and around block edges (6401 is
+    odd, so the edges fall on every position of a 16-byte vector), inside blocks, and one stretch is driven into
+    hard clipping; every output equals the oracle's."""
+    rng = np.random.default_rng(12)
+    nblk = 70
+    nsamp = 6401 * nblk + 3000
+    raw = _raw_stream(rng, nsamp, f0=-35.0, amp=8.0)
+    for b in (1, 2, 3, 9, 10, 17, 33, 34, 35, 64):               # around edge b: one zero byte each, I or Q rail
+        k = 6401 * b + int(rng.integers(-9, 10))
+        raw[2 * k + int(rng.integers(0, 2))] = 0
+    raw[2 * (6401 * 20 + 3000)] = 0                                # deep inside a block
+    lo, hi = 2 * 6401 * 40, 2 * 6401 * 43                         # three blocks of hard clipping (many 0x00 and 0xff)
+    n = np.arange((hi - lo) // 2)
+    clip = 127.5 + 400.0 * np.cos(2 * np.pi * (-600000.0 + 20.0) / 2.4e6 * n)
+    raw[lo:hi:2] = np.clip(np.round(clip), 0, 255).astype(np.uint8)
+    nbytes = (raw.size // 16) * 16
+    L = ol.lib()
+    st = L.orc_decim_new()
+    oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+    fill = L.orc_decim_feed(C.c_void_p(st), ol.ptr(raw), nbytes, ol.ptr(oi), ol.ptr(oq), 0, NS)
+    L.orc_decim_free(C.c_void_p(st))
+    gi = np.zeros(NS, np.float32); gq = np.zeros(NS, np.float32)
+    nout = C.c_uint32()
+    assert w.lib().wspr_decimate_u8(ol.ptr(raw), nbytes, ol.ptr(gi), ol.ptr(gq), C.byref(nout), 0) == 0
+    assert nout.value == fill == nblk
+    assert np.array_equal(gi[:fill], oi[:fill]) and np.array_equal(gq[:fill], oq[:fill])
+    # the same rows without any zero byte: the dot-product and masked paths alone
+    raw2 = np.maximum(raw, 1)
+    st = L.orc_decim_new()
+    fill = L.orc_decim_feed(C.c_void_p(st), ol.ptr(raw2), nbytes, ol.ptr(oi), ol.ptr(oq), 0, NS)
+    L.orc_decim_free(C.c_void_p(st))
+    assert w.lib().wspr_decimate_u8(ol.ptr(raw2), nbytes, ol.ptr(gi), ol.ptr(gq), C.byref(nout), 0) == 0
+    assert nout.value == fill == nblk
+    assert np.array_equal(gi[:fill], oi[:fill]) and np.array_equal(gq[:fill], oq[:fill])
+
+
 def _raw_stream(rng, nsamp, f0=40.0, amp=6.0):
     n = np.arange(nsamp)
     ph = 2 * np.pi * (-600000.0 + f0) / 2.4e6 * n
