@@ -405,10 +405,11 @@ def main():
             del src, dst
         if args.config == 5:
             kms = (C.c_double * 1)()
-            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 3, C.addressof(kms))
+            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 2, C.addressof(kms))   # settle
+            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 10, C.addressof(kms))
             k0_bytes = (RAW_BYTES + 360000) * nseg
             rms = (C.c_double * 1)()
-            L.wspr_calib_read(m["raw"].data_ptr(), RAW_BYTES, nseg, 3, C.addressof(rms))
+            L.wspr_calib_read(m["raw"].data_ptr(), RAW_BYTES, nseg, 10, C.addressof(rms))
             roof["front_end_K0"] = {"bound": "hbm", "avg_launch_ms": kms[0], "bytes_per_launch": k0_bytes,
                                     "achieved_GBs": k0_bytes / (kms[0] * 1e-3) / 1e9,
                                     "frac": k0_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,

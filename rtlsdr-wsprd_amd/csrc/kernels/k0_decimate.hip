@@ -272,23 +272,28 @@ void cic_block_sums_fast_kernel(const uint8_t* __restrict__ raw, size_t bytes_pe
     const int v_max = (int)((bytes_per_seg / 2 + 7) >> 3);        // vectors in a row
     const u4* __restrict__ vec = reinterpret_cast<const u4*>(raw + (size_t)seg * bytes_per_seg);
     unsigned acc[4] = {0u, 0u, 0u, 0u}, zacc[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 1
-    for (int r = 0; r < 3; ++r) {
-        const int v0 = vi_lo + 256 * r + lane;
-        u4 q[4];
+    // software pipeline: the next round's four loads (and, under the last round, the masked round's one) are
+    // issued before the current round is consumed, so a wave always has 64-80 bytes per lane in flight
+    int vt = vi_lo + 768 + lane, k_lo = 0, k_hi = (vt < vi_hi) ? 8 : 0;
+    if (lane == 62) { vt = vi_lo - 1; k_lo = lo - 8 * vt; k_hi = (k_lo < 8) ? 8 : 0; }       // k_lo == 8: the block starts on a vector
+    if (lane == 63) { vt = vi_hi; k_hi = hi - 8 * vt; }                                      // 0: it ends on one
+    const u4* __restrict__ p0 = vec + vi_lo + lane;
+    u4 qa[4], qb[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = __builtin_nontemporal_load(vec + v0 + 64 * u);
+    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 64 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) block_sum_vector<false>(q[u], kR + lo - 8 * (v0 + 64 * u), 0, 8, acc, zacc);
-    }
-    {   // the rest of the interior and the two edge vectors
-        int v = vi_lo + 768 + lane, k_lo = 0, k_hi = (v < vi_hi) ? 8 : 0;
-        if (lane == 62) { v = vi_lo - 1; k_lo = lo - 8 * v; k_hi = (k_lo < 8) ? 8 : 0; }     // k_lo == 8: the block starts on a vector
-        if (lane == 63) { v = vi_hi; k_hi = hi - 8 * v; }                                    // 0: it ends on one
-        const int vl = min(max(v, 0), v_max - 1);
-        const u4 q = __builtin_nontemporal_load(vec + vl);
-        block_sum_vector<true>(q, kR + lo - 8 * v, k_lo, k_hi, acc, zacc);
-    }
+    for (int u = 0; u < 4; ++u) qb[u] = __builtin_nontemporal_load(p0 + 256 + 64 * u);
+    const int wb0 = kR + lo - 8 * (vi_lo + lane);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qa[u], wb0 - 512 * u, 0, 8, acc, zacc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 512 + 64 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qb[u], wb0 - 2048 - 512 * u, 0, 8, acc, zacc);
+    const u4 qt = __builtin_nontemporal_load(vec + min(max(vt, 0), v_max - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qa[u], wb0 - 4096 - 512 * u, 0, 8, acc, zacc);
+    block_sum_vector<true>(qt, kR + lo - 8 * vt, k_lo, k_hi, acc, zacc);
     if (__any(((zacc[0] | zacc[1] | zacc[2] | zacc[3]) & 0x80808080u) != 0u)) {                      // clipping at the negative rail: exact path
         acc[0] = acc[1] = acc[2] = acc[3] = 0u;
         for (int v = vi_lo - 1 + lane; v <= vi_hi; v += 64) {
@@ -401,6 +406,52 @@ void cic_fir_kernel(const uint32_t* __restrict__ x2all, int nblocks, size_t seg_
     }
 }
 
+// Whole segments from a zero state need no integrator scan: the combs difference what the integrators summed,
+//     y2[b] = x2[b] - 2 x2[b-2] + x2[b-4]
+//           = R (S[b-1] + 2 S[b-2] + S[b-3]) + W[b] + W[b-1] - W[b-2] - W[b-3]        (mod 2^32, S = W = 0 for b < 0)
+// (x2[b] - x2[b-2] = sum over the two blocks of R x1(before) + W, and the x1 differences are block sums S),
+// exactly the value the scan + comb path produces because every step is arithmetic modulo 2^32.  One workgroup
+// forms 256 + 32 comb outputs per rail from coalesced 16-byte loads of the block sums and runs the 33-tap FIR
+// from LDS in the reference's tap order (rtlsdr_wsprd.c:220-234).
+__global__ __launch_bounds__(256)
+void cic_comb_fir_kernel(const int32_t* __restrict__ sums, int nblocks, float* __restrict__ dI, float* __restrict__ dQ,
+                         int* __restrict__ n_out) {
+    __shared__ int4 sb[256 + 32 + 3];                  // block sums of blocks m0-35 .. m0+255
+    __shared__ float y2[2][256 + 32];                  // comb outputs of blocks m0-32 .. m0+255
+    const int seg = blockIdx.y, tid = threadIdx.x, m0 = blockIdx.x * 256;
+    if (blockIdx.x == 0 && tid == 0 && n_out) n_out[seg] = nblocks < kMaxSamples ? nblocks : kMaxSamples;
+    const int4* __restrict__ s4 = reinterpret_cast<const int4*>(sums) + (size_t)seg * nblocks;
+    for (int e = tid; e < 256 + 35; e += 256) {
+        const int b = m0 - 35 + e;
+        sb[e] = (b >= 0 && b < nblocks) ? s4[b] : make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int e = tid; e < 256 + 32; e += 256) {        // comb output of block m0 - 32 + e = sums index e + 3
+        const int4 a0 = sb[e + 3], a1 = sb[e + 2], a2 = sb[e + 1], a3 = sb[e];
+        const unsigned yi = (unsigned)kR * ((unsigned)a1.x + 2u * (unsigned)a2.x + (unsigned)a3.x) +
+                            (unsigned)a0.z + (unsigned)a1.z - (unsigned)a2.z - (unsigned)a3.z;
+        const unsigned yq = (unsigned)kR * ((unsigned)a1.y + 2u * (unsigned)a2.y + (unsigned)a3.y) +
+                            (unsigned)a0.w + (unsigned)a1.w - (unsigned)a2.w - (unsigned)a3.w;
+        const bool live = (m0 - 32 + e) >= 0;          // before the start the reference's delay line holds 0.0f
+        y2[0][e] = live ? (float)(int32_t)yi : 0.0f;
+        y2[1][e] = live ? (float)(int32_t)yq : 0.0f;
+    }
+    __syncthreads();
+    const int m = m0 + tid;
+    if (m >= nblocks || m >= kMaxSamples) return;
+#pragma unroll
+    for (int rail = 0; rail < 2; ++rail) {
+        float acc = 0.0f;
+        for (int j = 0; j < 32; ++j) {
+            const float p = y2[rail][tid + j] * kFirTaps[j];
+            acc += p;
+        }
+        const float p = y2[rail][tid + 32] * kFirTaps[32];
+        acc += p;
+        (rail == 0 ? dI : dQ)[(size_t)seg * kIqStride + m] = acc;
+    }
+}
+
 // carry on: the last 36 integrator samples and the phase
 __global__ __launch_bounds__(128)
 void cic_carry_kernel(const uint32_t* __restrict__ x2all, int nblocks, size_t seg_samples, DecimState* __restrict__ states) {
@@ -442,12 +493,15 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     // whole segments take the wave-per-block kernel (sample indices fit 31 bits: rows below 4 GiB);
     // WSPR_K0_KERNEL=general keeps them on the kernel that also serves carried states
     static const bool general = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'g'; }();
-    if (!states && !general && bytes_per_seg < ((size_t)1 << 32))
+    if (!states && !general && bytes_per_seg < ((size_t)1 << 32)) {
         hipLaunchKernelGGL(cic_block_sums_fast_kernel, dim3((nblocks + 3) / 4, nseg), dim3(256), 0, st, raw,
                            bytes_per_seg, nblocks, sums);
-    else
-        hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
-                           bytes_per_seg, nblocks, sums, states);
+        hipLaunchKernelGGL(cic_comb_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, sums, nblocks,
+                           dI, dQ, n_out);
+        return;
+    }
+    hipLaunchKernelGGL(cic_block_sums_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw,
+                       bytes_per_seg, nblocks, sums, states);
     hipLaunchKernelGGL(cic_scan_kernel, dim3(nseg, 2), dim3(kScanThreads), 0, st, sums, nblocks, nsamp, x2, states);
     hipLaunchKernelGGL(cic_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, x2, nblocks, nsamp,
                        dI, dQ, n_out, states);
