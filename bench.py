@@ -385,7 +385,12 @@ def main():
                 tf = flop_each * n / (t_ms * 1e-3) / 1e12
                 return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
                         "frac_of_no_fma_bound": tf / VALU_NOFMA_TF}
+            mtf = C.c_double(0.0)
+            L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
+            L.wspr_calib_valu(20, C.addressof(mtf))
             roof["valu"] = {"peak_TFs": VALU_PEAK_TF, "no_fma_bound_TFs": VALU_NOFMA_TF,
+                            # register-only v_pk_mul_f32 + v_pk_add_f32 chains on every SIMD: the practical ceiling
+                            "measured_no_fma_TFs": mtf.value,
                             "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
                                     "half the FMA peak",
                             "K4_lag_scan (demod_tile_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),

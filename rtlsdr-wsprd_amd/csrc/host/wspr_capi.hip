@@ -290,6 +290,28 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
 }
 
+int wspr_calib_valu(int launches, double* tflops) {
+    try {
+        Context& c = Context::get();
+        TempDev out(64);
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        wspr::launch_calib_valu((float*)out.p, 256, c.stream());                  // settle the clocks
+        HIP_TRY(hipEventRecord(e0, c.stream()));
+        double flops = 0;
+        for (int i = 0; i < launches; ++i) flops += wspr::launch_calib_valu((float*)out.p, 2048, c.stream());
+        HIP_TRY(hipEventRecord(e1, c.stream()));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_calib_valu", e); }
+}
+
 int wspr_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -646,6 +646,60 @@ void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ
     if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
 }
 
+// Scalar-table form of freq_tile_kernel: a hypothesis owns three whole waves (lane = symbol, 162 of 192 lanes),
+// so its one table is wave-uniform and is read through the scalar cache straight into SGPR operands of the packed
+// multiplies, as in the lag scan -- no 40 KB of tables in LDS (three workgroups per CU instead of one) and no
+// two 16-byte LDS reads per lane and step.
+constexpr int kFqThreads = 960;                                   // 5 hypotheses x 3 waves
+constexpr int kFqPerThread = (kNSymD * kFsChunk + kFqThreads - 1) / kFqThreads;      // 6 samples staged per thread and chunk
+
+__global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                        const FineState* __restrict__ items, const int* __restrict__ item_list,
+                        const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+    __shared__ float2 tile[kNSymD][kFsChunk + 1];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const FineState st = items[item_list[slot]];
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = wave / 3, sym = (wave - 3 * f) * 64 + (tid & 63);
+    const bool working = sym < kNSymD;
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps);
+
+    float2 nxt[kFqPerThread];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < kFqPerThread; ++u) {
+            const int e = u * kFqThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
+            const int k = st.shift + kSps * row + kFsChunk * c + col;
+            const bool ok = (e < kNSymD * kFsChunk) && (k > 0) && (k < np);
+            nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+    };
+    fetch(0);
+    ToneAcc acc;
+    acc.clear();
+    for (int c = 0; c < kSps / kFsChunk; ++c) {
+        __syncthreads();                                             // the previous chunk has been consumed
+#pragma unroll
+        for (int u = 0; u < kFqPerThread; ++u) {
+            const int e = u * kFqThreads + tid;
+            if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
+        }
+        __syncthreads();
+        if (c + 1 < kSps / kFsChunk) fetch(c + 1);
+        if (working) {
+#pragma unroll 8
+            for (int jj = 0; jj < kFsChunk; ++jj) {
+                const int j = kFsChunk * c + jj;
+                acc.step(tile[sym][jj], gt[2 * j], gt[2 * j + 1]);
+            }
+        }
+    }
+    if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
+}
+
 // The same scan for a DRIFTING candidate: every (hypothesis, symbol) has its own four tone phasors and each
 // of them is used by exactly one lane, so there is nothing to share and no table: a lane carries the four
 // recurrences (wsprd.c:158-188) in registers next to its accumulators, 12 + 16 packed instructions per sample.
@@ -859,6 +913,11 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
             return true;
         }();
         (void)once;
+        static const bool lds_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return e && e[0] == 'l'; }();
+        if (!lds_tab)
+            hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
+                               list_shared, tabs, reinterpret_cast<float4*>(pw));
+        else
         hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
                            samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
@@ -929,6 +988,38 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
 #undef WSPR_LAUNCH_TILE
     hipLaunchKernelGGL(demod_metric_kernel, dim3((nitems * nlag + 63) / 64), dim3(64), 0, st, pw4, items, nitems,
                        mode, nlag, minsync1, sync_out, sym_out, rms_out, t.sync);
+}
+
+// Calibration for the vector rooflines: register-only chains of separately rounded packed multiplies and adds
+// (the instruction mix of the matched-filter sums, nothing else), enough waves to fill every SIMD.  What it
+// sustains is the practical ceiling of v_pk_mul_f32 / v_pk_add_f32 at the clock the GPU holds under this load.
+namespace {
+__global__ __launch_bounds__(256)
+void calib_valu_kernel(float* __restrict__ out, int iters) {
+    v2f a[8], m = {1.0000001f, 0.9999999f}, c = {1e-9f, -1e-9f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (v2f){1.0f + threadIdx.x * 1e-6f + k, 1.0f - k * 1e-3f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const v2f p = a[k] * m;            // v_pk_mul_f32
+                a[k] = p + c;                      // v_pk_add_f32 (contraction is off in this file)
+            }
+        }
+    }
+    v2f s = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s = s + a[k];
+    if (s.x == 123.456f) out[0] = s.y;             // keeps the chains alive; practically never true
+}
+}  // namespace
+// flops (one per multiply or add and lane half) of one launch
+double launch_calib_valu(float* out, int iters, hipStream_t st) {
+    const int wgs = 256 * 8;                       // 8 workgroups of 4 waves per CU
+    hipLaunchKernelGGL(calib_valu_kernel, dim3(wgs), dim3(256), 0, st, out, iters);
+    return (double)wgs * 256 * iters * 8 * 8 * 4;  // 8 x 8 (mul + add) pairs of 2 lanes-halves
 }
 
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st) {

@@ -83,6 +83,7 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
 void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                          int samples, float* ps, float* psavg, const DeviceTables& t, hipStream_t st);
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
+double launch_calib_valu(float* out, int iters, hipStream_t st);
 void launch_calib_read(const uint8_t* raw, size_t bytes_per_seg, int nseg, unsigned* out, hipStream_t st);
 // psavg: scratch, nseg * kPsStride floats (time-averaged spectrum per segment)
 // K2a alone: psavg[seg][kPsStride] = sum over time blocks of ps, in block order (wsprd.c:556-561)
