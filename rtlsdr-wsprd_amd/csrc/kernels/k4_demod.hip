@@ -504,6 +504,127 @@ void demod_drift_kernel(const float* __restrict__ dI, const float* __restrict__ 
     }
 }
 
+// -----------------------------------------------------------------------------
+// Lag scan (mode 0: 33 lags, step 8) of a DRIFT-FREE candidate, three symbols per lane.
+//
+// The candidate has ONE phasor table, read through the scalar cache into SGPR operands.  With one (symbol, lag)
+// per lane (demod_tile_kernel<8, true>) a wave issues 16 packed instructions per table entry and then waits for
+// the next scalar load and LDS read: its vector pipe is busy 61 % of the time (SQ counters).  Here a lane runs
+// the same lag of THREE consecutive symbols (lane = (symbol triple q, lag m), L = 33 q + m, 54 x 33 = 1 782
+// lanes = 7 workgroups of 256 at 99.4 %): a table entry serves three 16-instruction accumulator updates, the
+// address arithmetic is shared, and consecutive lanes read consecutive 8-byte words of the lag-step-transposed
+// sample tile (conflict-free without padding).  Same operations per accumulator as demod_kernel => identical bits.
+constexpr int kL3Threads = 256;
+constexpr int kL3Lanes = (kNSymD / 3) * 33;                 // 1 782 (symbol triple, lag) pairs per candidate
+constexpr int kL3Wgs = (kL3Lanes + kL3Threads - 1) / kL3Threads;
+constexpr int kL3MaxSyms = 3 * ((kL3Threads + 32) / 33 + 1);       // symbols one workgroup can touch: 27
+constexpr int kL3Span = kSps * kL3MaxSyms + 8 * 32;         // samples staged per workgroup
+constexpr int kL3Pitch = kL3Span / 8 + 1;                   // 8-byte words per tile row
+
+__global__ __launch_bounds__(kL3Threads)
+void demod_lag3_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                       const FineState* __restrict__ items, const int* __restrict__ item_list,
+                       const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+    extern __shared__ __attribute__((aligned(16))) char l3_smem[];
+    float2* tile = reinterpret_cast<float2*>(l3_smem);
+    constexpr int nlag = 33;
+    const int item = item_list[blockIdx.y];
+    const FineState st = items[item];
+    const int tid = threadIdx.x;
+    const int L0 = blockIdx.x * kL3Threads, L = L0 + tid;
+    const int q0 = L0 / nlag;                                // first symbol triple of this workgroup
+    const int q1 = min(kNSymD / 3 - 1, (L0 + kL3Threads - 1) / nlag);
+    const int sym0 = 3 * q0, nsym = 3 * (q1 - q0 + 1);
+    const int span = kSps * nsym + 8 * 32;
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int kbase = st.shift_coarse - 128 + kSps * sym0;
+    for (int e0 = tid; e0 < span; e0 += 4 * kL3Threads) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kL3Threads, k = kbase + e;
+            const bool ok = (e < span) && (k > 0) && (k < np);   // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
+            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kL3Threads;
+            if (e < span) tile[(e & 7) * kL3Pitch + (e >> 3)] = v[u];
+        }
+    }
+    __syncthreads();
+    if (L >= kL3Lanes) return;
+    const int q = L / nlag, m = L - q * nlag;
+    // e = 8 m + 256 (sym - sym0) + j: row j & 7, column m + 32 (sym - sym0) + (j >> 3)
+    const float2* __restrict__ col = tile + m + (kSps / 8) * (3 * (q - q0));
+    const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
+                                      (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
+    ToneAcc acc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r].clear();
+    // Two steps form a stage: their table entries (one 64-byte scalar load) and their 2 x 3 samples.  The loads
+    // of stage k+1 are issued before stage k is consumed and waited for one stage later, when they are ~800
+    // cycles old: scalar loads return out of order, so every wait on them is lgkmcnt(0); placed by hand at the
+    // top of a stage it only sees loads that have had a whole stage to land.
+    struct Stage { float4 c[2], s[2]; float2 d[2][3]; };
+    auto issue = [&](Stage& g, int j) {                      // j even; clamped past the end (values unused)
+        const int jj = j < kSps ? j : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            g.c[u] = gtab[2 * (jj + u)];
+            g.s[u] = gtab[2 * (jj + u) + 1];
+            const float2* __restrict__ t0 = col + ((jj + u) >> 3) + ((jj + u) & 7) * kL3Pitch;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) g.d[u][r] = t0[(kSps / 8) * r];
+        }
+    };
+    auto consume = [&](const Stage& g) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 c4 = g.c[u], s4 = g.s[u];
+            const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+            v2f p[3][8];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const v2f xx = {g.d[u][r].x, g.d[u][r].x}, yy = {g.d[u][r].y, g.d[u][r].y};
+                p[r][0] = xx * c01; p[r][1] = xx * c23; p[r][2] = xx * s01; p[r][3] = xx * s23;
+                p[r][4] = yy * s01; p[r][5] = yy * s23; p[r][6] = yy * c01; p[r][7] = yy * c23;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {               // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
+                acc[r].i01 = acc[r].i01 + p[r][0]; acc[r].i23 = acc[r].i23 + p[r][1];
+                acc[r].q01 = acc[r].q01 - p[r][2]; acc[r].q23 = acc[r].q23 - p[r][3];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[r].i01 = acc[r].i01 + p[r][4]; acc[r].i23 = acc[r].i23 + p[r][5];
+                acc[r].q01 = acc[r].q01 + p[r][6]; acc[r].q23 = acc[r].q23 + p[r][7];
+            }
+        }
+    };
+    Stage A, B;
+    issue(A, 0);
+#pragma unroll 1
+    for (int j0 = 0; j0 < kSps; j0 += 4) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): stage A has landed
+        __builtin_amdgcn_sched_barrier(0);
+        issue(B, j0 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // stage B has landed
+        __builtin_amdgcn_sched_barrier(0);
+        issue(A, j0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        pw_out[((size_t)item * nlag + m) * kNSymD + 3 * q + r] = acc[r].amplitudes();
+}
+
 // folds the 162 per-symbol tone amplitudes of one (candidate, lag) in symbol order
 __global__ __launch_bounds__(64)
 void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restrict__ items, int nitems,
@@ -706,7 +827,7 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
 // Staging, thread mapping and output layout are those of freq_tile_kernel, so freq_metric_kernel picks the
 // winner and forms the first rung's soft symbols for drifting candidates too (the general kernel ran the five
 // hypotheses as five workgroups and the first rung as a sixth pass over the samples).
-__global__ __launch_bounds__(kFsThreads)
+__global__ __launch_bounds__(kFsThreads) __attribute__((amdgpu_waves_per_eu(7, 8)))     // <= 72 VGPRs: two workgroups per CU
 void freq_drift_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin, float fstep,
                        float4* __restrict__ pw_out) {
@@ -966,11 +1087,23 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
     static const int scalar_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return (e && e[0] == 'l') ? 0 : 1; }();
+    // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one symbol per lane)
+    static const bool lag3_kernel = [] {
+        const char* e = getenv("WSPR_K4_LAG");
+        if (e && e[0] == 't') return false;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&demod_lag3_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * kL3Pitch * sizeof(float2)));
+        return true;
+    }();
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
     static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
-        if (n_shared > 0)                                                                                        \
+        if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lag3_kernel)                                 \
+            hipLaunchKernelGGL(demod_lag3_kernel, dim3(kL3Wgs, n_shared), dim3(kL3Threads),                      \
+                               (size_t)8 * kL3Pitch * sizeof(float2), st, dI, dQ, samples, items, list_shared,   \
+                               tabs, pw4);                                                                       \
+        else if (n_shared > 0)                                                                                   \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
                                threads(kTileSymsShared), 8192 + tile_bytes(kTileSymsShared), st, dI, dQ, samples, \
                                items, list_shared, mode, nlag, minsync1, tabs, pw4, scalar_tab);                 \
