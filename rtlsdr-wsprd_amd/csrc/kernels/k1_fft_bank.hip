@@ -393,12 +393,8 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
     do {                                                                                                    \
         const int per_wg = R * kWavesPerWg;                                                                 \
         const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (per_wg + 1) * sizeof(float); \
-        static const bool once = [&] {                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_bank_kernel<R>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-            return true;                                                                                    \
-        }();                                                                                                \
-        (void)once;                                                                                         \
+        static std::atomic<unsigned> opted{0};                                                              \
+        lds_opt_in(reinterpret_cast<const void*>(&fft_bank_kernel<R>), lds, opted);                         \
         dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);                                             \
         hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), lds, st, dI, dQ, seg_list, blocks, ps,      \
                            t.window, t.twiddle);                                                            \

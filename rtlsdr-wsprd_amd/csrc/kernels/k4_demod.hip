@@ -1028,19 +1028,16 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
         const size_t fs_lds = kNFreq * 2 * kSps * sizeof(float4) + (size_t)kNSymD * (kFsChunk + 1) * sizeof(float2);   // 83 KB
-        static const bool once = [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&freq_tile_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds);
-            return true;
-        }();
-        (void)once;
+        static std::atomic<unsigned> fs_opted{0};
         static const bool lds_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return e && e[0] == 'l'; }();
         if (!lds_tab)
             hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
                                list_shared, tabs, reinterpret_cast<float4*>(pw));
-        else
-        hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
-                           samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
+        else {
+            lds_opt_in(reinterpret_cast<const void*>(&freq_tile_kernel), fs_lds, fs_opted);
+            hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
+                               samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
+        }
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
                            reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
                            sync_out, sym_out, rms_out, t.sync);
@@ -1088,13 +1085,9 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     float4* pw4 = reinterpret_cast<float4*>(pw);
     static const int scalar_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return (e && e[0] == 'l') ? 0 : 1; }();
     // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one symbol per lane)
-    static const bool lag3_kernel = [] {
-        const char* e = getenv("WSPR_K4_LAG");
-        if (e && e[0] == 't') return false;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&demod_lag3_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * kL3Pitch * sizeof(float2)));
-        return true;
-    }();
+    static const bool lag3_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
+    static std::atomic<unsigned> l3_opted{0};
+    if (lag3_kernel) lds_opt_in(reinterpret_cast<const void*>(&demod_lag3_kernel), 8 * kL3Pitch * sizeof(float2), l3_opted);
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
     static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \

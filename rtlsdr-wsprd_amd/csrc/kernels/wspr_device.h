@@ -11,6 +11,7 @@
 // (window, twiddles, sync vector, subtraction low-pass taps).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 namespace wspr {
@@ -83,6 +84,16 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
 void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                          int samples, float* ps, float* psavg, const DeviceTables& t, hipStream_t st);
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
+
+// Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device, once per device (a process that drives
+// several devices through wspr_set_device reaches every launch site from each of them).
+inline void lds_opt_in(const void* kernel, size_t bytes, std::atomic<unsigned>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    if (done.load(std::memory_order_relaxed) & (1u << dev)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done.fetch_or(1u << dev, std::memory_order_relaxed);
+}
 double launch_calib_valu(float* out, int iters, hipStream_t st);
 void launch_calib_read(const uint8_t* raw, size_t bytes_per_seg, int nseg, unsigned* out, hipStream_t st);
 // psavg: scratch, nseg * kPsStride floats (time-averaged spectrum per segment)
