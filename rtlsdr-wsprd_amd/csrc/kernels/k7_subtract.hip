@@ -17,6 +17,7 @@
 //                      conflict-free; the epilogue subtracts c*r/norm in place.
 // Bound: fp32 VALU (64 MFLOP of separately rounded mul/add per job), not HBM.
 #include "wspr_device.h"
+#include <cstdlib>
 #include "glibc_sincosf.h"
 #include "phase_runs.h"
 
@@ -198,6 +199,119 @@ void sub_filter_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
     }
 }
 
+// Eight outputs per lane, taps from scalar registers.  In the kernel above a lane's four outputs share each
+// freshly read sample and the taps come from LDS: per four taps a wave issues 32 packed multiply/adds against
+// one 16-byte and four 8-byte LDS reads, and with four SIMDs on one LDS the return path is ~75 % busy.  Here a
+// lane slides an eight-sample register window (16 packed instructions per 8-byte LDS read) and the taps, the
+// same for every lane, arrive through the scalar cache eight at a time, issued a stage (eight taps = 128
+// packed instructions) before they are needed and waited for when a stage old (see demod_lag3_kernel).  The
+// tile is stored transposed by 8, so the per-tap read of consecutive lanes is consecutive 8-byte words.
+// Each output is still one serial 360-term sum in tap order: identical bits.
+constexpr int kFir8PerLane = 8;
+constexpr int kFir8Out = kFirThreads * kFir8PerLane;              // 2048 outputs per workgroup
+constexpr int kFir8Span = kFir8Out + kLpfTaps - 1;                // 2407 inputs
+constexpr int kFir8Pitch = (kFir8Span + 7) / 8 + 1;               // transposed-by-8 row pitch (8-byte words)
+static_assert(kLpfTaps % 8 == 0, "taps are consumed eight at a time");
+
+__global__ __launch_bounds__(kFirThreads)
+void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
+                        const SubJob* __restrict__ jobs, const float* __restrict__ perjob,
+                        const float* __restrict__ lpf, const float* __restrict__ lpf_part) {
+    __shared__ float2 tile[8 * kFir8Pitch];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const SubJob* job = jobs + blockIdx.y;
+    const float2* __restrict__ ref = reinterpret_cast<const float2*>(perjob + (size_t)blockIdx.y * kSubPerJob);
+    const float2* __restrict__ cc = ref + kSigLen;
+    const int n0 = blockIdx.x * kFir8Out;
+    // the reference filters a zero-padded copy (360 leading zeros); outside the signal the products are zero
+    for (int e0 = tid; e0 < kFir8Span; e0 += 4 * kFirThreads) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kFirThreads, n = n0 - kLpfTaps / 2 + e;
+            v[u] = (e < kFir8Span && n >= 0 && n < kSigLen) ? cc[n] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * kFirThreads;
+            if (e < kFir8Span) tile[(e & 7) * kFir8Pitch + (e >> 3)] = v[u];
+        }
+    }
+    __syncthreads();
+
+    // outputs n0 + 8 tid + r, r = 0..7; input of tap j for output r: e = 8 tid + r + j
+    v2f acc[8], x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = (v2f){0.0f, 0.0f};
+        const float2 t = tile[r * kFir8Pitch + tid];
+        x[r] = (v2f){t.x, t.y};
+    }
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(lpf);
+    struct Stage { float4 wa, wb; float2 in[8]; };
+    auto issue = [&](Stage& g, int j) {                      // taps j..j+7 and the samples that enter the window under them
+        const int jj = j < kLpfTaps ? j : 0;
+        g.wa = w4[jj / 4];
+        g.wb = w4[jj / 4 + 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                        // e = 8 tid + 8 + jj + u: row u (jj is a multiple of 8)
+            g.in[u] = tile[u * kFir8Pitch + tid + 1 + (jj >> 3)];
+        }
+    };
+    auto consume = [&](const Stage& g) {
+        const float w[8] = {g.wa.x, g.wa.y, g.wa.z, g.wa.w, g.wb.x, g.wb.y, g.wb.z, g.wb.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const v2f wu = {w[u], w[u]};
+            v2f p[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) p[r] = wu * x[(u + r) & 7];          // window slot (u + r) & 7 holds sample e = 8 tid + r + j + u
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = acc[r] + p[r];
+            x[u & 7] = (v2f){g.in[u].x, g.in[u].y};                           // the oldest sample leaves, e = 8 tid + 8 + j + u enters
+        }
+    };
+    Stage A, B;
+    issue(A, 0);
+#pragma unroll 1
+    for (int j = 0; j < kLpfTaps; j += 16) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): stage A has landed
+        __builtin_amdgcn_sched_barrier(0);
+        issue(B, j + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 8 < kLpfTaps) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(A, j + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = n0 + 8 * tid + r;
+        if (n >= kSigLen) break;
+        float norm = 1.0f;                                   // wsprd.c:397-404
+        if (n < kLpfTaps / 2)                    norm = lpf_part[kLpfTaps / 2 + n];
+        else if (n > kSigLen - 1 - kLpfTaps / 2) norm = lpf_part[kLpfTaps / 2 + kSigLen - 1 - n];
+        const int k = job->shift + n;
+        if (k > 0 && k < np) {
+            float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
+            float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
+            const float2 rr = ref[n];
+            const float si = acc[r].x, sq = acc[r].y;
+            const float a = si * rr.x, b = sq * rr.y, c = si * rr.y, d = sq * rr.x;
+            const float ri = a - b, rq = c + d;
+            xi[k] = xi[k] - ri / norm;
+            xq[k] = xq[k] - rq / norm;
+        }
+    }
+}
+
 // ---- receiver normalisation, rtlsdr_wsprd.c:284-305 -------------------------
 __global__ __launch_bounds__(1024)
 void normalise_kernel(float* __restrict__ dI, float* __restrict__ dQ, const int* __restrict__ n_valid,
@@ -234,8 +348,14 @@ void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int 
     PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch + (size_t)njobs * kSubPerJob);
     hipLaunchKernelGGL(sub_runs_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, tables);
     hipLaunchKernelGGL(sub_ref_kernel, dim3(kNSymD / kSymPerWg, njobs), dim3(256), 0, st, dI, dQ, samples, jobs, tables, perjob);
-    hipLaunchKernelGGL(sub_filter_kernel, dim3((kSigLen + kFirOut - 1) / kFirOut, njobs), dim3(kFirThreads), 0, st,
-                       dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
+    // WSPR_K7_FIR=4: the four-outputs-per-lane kernel with the taps in LDS
+    static const bool fir4 = [] { const char* e = getenv("WSPR_K7_FIR"); return e && e[0] == '4'; }();
+    if (fir4)
+        hipLaunchKernelGGL(sub_filter_kernel, dim3((kSigLen + kFirOut - 1) / kFirOut, njobs), dim3(kFirThreads), 0, st,
+                           dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
+    else
+        hipLaunchKernelGGL(sub_filter8_kernel, dim3((kSigLen + kFir8Out - 1) / kFir8Out, njobs), dim3(kFirThreads), 0, st,
+                           dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
 }
 
 // Working copy of resident input: rows of `samples` floats (16-byte aligned, stride a multiple of 4) into
