@@ -407,6 +407,11 @@ def main():
             t0 = time.perf_counter()
             L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
             roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
+            L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
+            t0 = time.perf_counter()
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
+            roof["measured_copy16_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9     # 16 bytes per lane
             del src, dst
         if args.config == 5:
             kms = (C.c_double * 1)()

@@ -265,6 +265,8 @@ int wspr_calib_read(const void *d_raw, size_t bytes_per_seg, int nseg, int iters
 /* PMC calibration: `iters` launches of a 4-byte-per-lane stream copy of nfloats floats on the
  * library's stream (known traffic: 4*nfloats bytes read and written per launch). */
 int wspr_calib_copy(const void *d_src, void *d_dst, size_t nfloats, int iters);
+/* The same copy with 16 bytes per lane (nfloats a multiple of 4, 16-byte aligned buffers). */
+int wspr_calib_copy16(const void *d_src, void *d_dst, size_t nfloats, int iters);
 /* Vector-pipe calibration for the VALU rooflines: `launches` launches of register-only chains of separately
  * rounded packed multiplies and adds (v_pk_mul_f32 + v_pk_add_f32, no FMA) that fill every SIMD; *tflops =
  * sustained TFLOP/s (one flop per multiply or add), i.e. the practical ceiling of the decoder's arithmetic at the

@@ -290,6 +290,16 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
 }
 
+int wspr_calib_copy16(const void* d_src, void* d_dst, size_t nfloats, int iters) {
+    try {
+        if ((nfloats & 3) || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) return -1;
+        Context& c = Context::get();
+        for (int i = 0; i < iters; ++i) wspr::launch_calib_copy16((const float*)d_src, (float*)d_dst, nfloats, c.stream());
+        c.sync();
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_calib_copy16", e); }
+}
+
 int wspr_calib_valu(int launches, double* tflops) {
     try {
         Context& c = Context::get();

@@ -380,6 +380,17 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const float* __restrict
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, st, src, dst, n);
 }
+// the same copy with 16 bytes per lane (n a multiple of 4, 16-byte aligned buffers): the ceiling a kernel that
+// moves whole 16-byte words could reach
+namespace {
+__global__ __launch_bounds__(256) void calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(calib_copy16_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), n / 4);
+}
 
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                      int samples, float* ps, const DeviceTables& t, hipStream_t st) {
