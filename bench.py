@@ -393,9 +393,9 @@ def main():
                             "measured_no_fma_TFs": mtf.value,
                             "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
                                     "half the FMA peak",
-                            "K4_lag_scan (demod_tile_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
-                            "K4_freq_scan_first_rung (freq_tile_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
-                            "K7_subtract (sub_runs + sub_ref + sub_filter kernels)": valu(K7_FLOP, vms[3], vms[1])}
+                            "K4_lag_scan (demod_lag3_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
+                            "K4_freq_scan_first_rung (freq_scalar_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
+                            "K7_subtract (sub_runs + sub_ref + sub_filter8 kernels)": valu(K7_FLOP, vms[3], vms[1])}
         # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
         # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
         if args.config != 5:
