@@ -392,6 +392,211 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
         }
     }
 }
+
+// The same search with ONE lane per (candidate, lag) holding all three frequency bins (full-length records).
+// coarse_sync_kernel issues eight LDS reads per lane and symbol for ten packed instructions, three waves per
+// candidate pair: with four SIMDs on one LDS the return path is busy 64 clocks per 40 of arithmetic.  The three
+// bins a candidate searches read only FOUR distinct tone sets D_j = bin if0 - 2 + j (rows j + 2 t of the ten
+// bins if0 - 5 .. if0 + 4): a lane keeps one running (sync, power) pair per tone set for the whole frame --
+// that is pattern 1 (no drift) of bin ifr = D_(fi+1) and, up to symbol 80, the shared history of the two
+// drifting patterns -- plus the six drifting sums after the fan-out at symbol 81.  Per symbol: TEN amplitudes
+// read once, 18 packed instructions before the fan-out and 38 after it for nine hypotheses (28 % fewer vector
+// instructions, 58 % fewer LDS reads).  Every sum still receives the reference's terms one by one in its order;
+// the packed pairs are (D_0, D_1) and (D_2, D_3), whose operands are adjacent rows = adjacent registers.
+// One wave = two candidates; the amplitudes are staged in two halves of 81 symbols (196 columns of the ten
+// rows: 15.7 KB per wave, ten waves per CU instead of five with whole rows).
+constexpr int kCsChunkSyms = 81;                                 // the fan-out symbol 81 opens the second half
+constexpr int kCsChunkCols = 196;                                // 2 x 80 + 32 lags, widened to whole 16-byte words
+constexpr int kCsChunkWords = 10 * (kCsChunkCols / 4);           // 490 16-byte words per candidate and half
+constexpr int kCsChunkLoads = (2 * kCsChunkWords + 63) / 64;     // 16 per lane
+static_assert(kNSymD == 2 * kCsChunkSyms, "two halves of 81 symbols");
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void coarse_sync_lane_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list,
+                             DevCand* __restrict__ cand, const int* __restrict__ npk, int maxdrift, const SyncBits pr3) {
+    __shared__ __attribute__((aligned(16))) float amp[2][10 * kCsChunkCols];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int blocks = kMaxBlocks;
+    const int lane = threadIdx.x, half = lane >> 5, k0 = (lane & 31) - 10;
+    const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
+    const float* __restrict__ P = ps + (size_t)seg * kPsBins * kPsTPitch;
+    const int ncand = min(npk[seg], kMaxCand);
+    const int npat = (maxdrift > 0) ? 3 : 1;
+    const uint32_t w0 = pr3.w[0], w1 = pr3.w[1], w2 = pr3.w[2], w3 = pr3.w[3], w4 = pr3.w[4], w5 = pr3.w[5];
+    auto sign_of = [&](int k) {                                  // sync-vector sign as a scalar float (wave-uniform)
+        const uint32_t w = k < 96 ? (k < 32 ? w0 : (k < 64 ? w1 : w2)) : (k < 128 ? w3 : (k < 160 ? w4 : w5));
+        return __int_as_float(__builtin_amdgcn_readfirstlane((int)(((w >> (k & 31)) & 1u) ? 0x3f800000u : 0xbf800000u)));
+    };
+
+    for (int pair = blockIdx.y; 2 * pair < ncand; pair += gridDim.y) {
+        const int c_a = 2 * pair, c_b = 2 * pair + 1;
+        const int if0_a = (int)((double)cand[(size_t)seg * kMaxCand + c_a].freq / kHalfDf + 256.0);
+        const int if0_b = (c_b < ncand) ? (int)((double)cand[(size_t)seg * kMaxCand + c_b].freq / kHalfDf + 256.0) : if0_a;
+        // staged row q = bin if0 - 5 + q, q = 0..9
+        const float* __restrict__ src_a = P + (size_t)(if0_a - 5 - kPsBin0) * kPsTPitch;
+        const float* __restrict__ src_b = P + (size_t)(if0_b - 5 - kPsBin0) * kPsTPitch;
+        // half h covers columns t0 .. t0 + 195 with t0 = -12 (lags down to -10) or 152
+        auto stage = [&](int t0) {
+            constexpr int kRound = 8;                            // loads in flight per lane
+            static_assert(kCsChunkLoads % kRound == 0, "whole rounds");
+#pragma unroll 1
+            for (int u0 = 0; u0 < kCsChunkLoads; u0 += kRound) {
+                f4 pre[kRound];
+#pragma unroll
+                for (int u = 0; u < kRound; ++u) {
+                    const int e = min(lane + 64 * (u0 + u), 2 * kCsChunkWords - 1);
+                    const int cb = e >= kCsChunkWords, el = e - cb * kCsChunkWords, q = el / (kCsChunkCols / 4), w = el - q * (kCsChunkCols / 4);
+                    const int t = t0 + 4 * w;
+                    const float* __restrict__ row = (cb ? src_b : src_a) + (size_t)q * kPsTPitch;
+                    // a negative time index reads the previous bin's row, 347 + index (Q2): t = -12, -8, -4 of the first half
+                    const float* __restrict__ from = (t >= 0) ? row + t : row - kPsTPitch + blocks + t;
+                    if (t >= 0) {
+                        pre[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(from));
+                    } else {
+                        pre[u].x = from[0]; pre[u].y = from[1]; pre[u].z = from[2]; pre[u].w = from[3];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kRound; ++u) {
+                    const int e = lane + 64 * (u0 + u);
+                    if (e < 2 * kCsChunkWords) {
+                        f4 r;
+                        r.x = sqrtf(pre[u].x); r.y = sqrtf(pre[u].y); r.z = sqrtf(pre[u].z); r.w = sqrtf(pre[u].w);
+                        *reinterpret_cast<f4*>(&amp[0][0] + 4 * e) = r;       // amp[1] follows amp[0]
+                    }
+                }
+            }
+        };
+        // per-tone-set sums for the whole frame: S01 = (D_0, D_1), S23 = (D_2, D_3); tone t of D_j = a[j + 2 t]
+        cs2 S01 = {0.f, 0.f}, W01 = {0.f, 0.f}, S23 = {0.f, 0.f}, W23 = {0.f, 0.f};
+        cs2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
+        auto bins = [&](int k, const float (&a)[10]) {
+            const float sg = sign_of(k);
+            const cs2 A0 = {a[0], a[1]}, A1 = {a[2], a[3]}, A2 = {a[4], a[5]}, A3 = {a[6], a[7]}, A4 = {a[8], a[9]};
+            m01 = ((A1 + A3) - (A0 + A2)) * sg;                   // tones of (D_0, D_1): pairs 0..3
+            m23 = ((A2 + A4) - (A1 + A3)) * sg;                   // tones of (D_2, D_3): pairs 1..4
+            S01 = S01 + m01;
+            S23 = S23 + m23;
+            W01 = (((W01 + A0) + A1) + A2) + A3;
+            W23 = (((W23 + A1) + A2) + A3) + A4;
+        };
+        // ---- symbols 0..80 ----
+        __syncthreads();                                         // the previous pair has been consumed
+        stage(-12);
+        __syncthreads();
+        {
+            const float* __restrict__ A = amp[half] + (k0 + 12);
+            auto load = [&](int kk, float (&a)[10]) {
+#pragma unroll
+                for (int q = 0; q < 10; ++q) a[q] = A[q * kCsChunkCols + 2 * kk];
+            };
+            float a0[10], a1[10];
+            load(0, a0);
+#pragma unroll 1
+            for (int k = 0; k < 80; k += 2) {
+                load(k + 1, a1);
+                bins(k, a0);
+                load(k + 2, a0);
+                bins(k + 1, a1);
+            }
+            bins(80, a0);
+        }
+        // fan-out: pattern 0 of bin fi (drift < 0) continues D_(fi+1), pattern 2 (drift > 0) continues D_fi
+        cs2 X0S = {S01.y, S23.x}, X0W = {W01.y, W23.x};          // pattern 0 of fi = 0, 1 (reads D_0, D_1 from 82 on)
+        float X0S2 = S23.y, X0W2 = W23.y;                        // pattern 0 of fi = 2 (reads D_2)
+        float X2S0 = S01.x, X2W0 = W01.x;                        // pattern 2 of fi = 0 (reads D_1)
+        cs2 X2S = {S01.y, S23.x}, X2W = {W01.y, W23.x};          // pattern 2 of fi = 1, 2 (reads D_2, D_3)
+        // ---- symbols 81..161 ----
+        __syncthreads();
+        stage(152);
+        __syncthreads();
+        {
+            const float* __restrict__ A = amp[half] + (k0 + 2 * kCsChunkSyms - 152);
+            auto load = [&](int kk, float (&a)[10]) {            // kk = symbol - 81
+#pragma unroll
+                for (int q = 0; q < 10; ++q) a[q] = A[q * kCsChunkCols + 2 * kk];
+            };
+            auto drifting = [&](const float (&a)[10]) {          // after bins(k, a): m01 / m23 are this symbol's
+                const cs2 A0 = {a[0], a[1]}, A1 = {a[2], a[3]}, A2 = {a[4], a[5]}, A3 = {a[6], a[7]}, A4 = {a[8], a[9]};
+                X0S = X0S + m01;                                 // (D_0, D_1)
+                X0W = (((X0W + A0) + A1) + A2) + A3;
+                X2S = X2S + m23;                                 // (D_2, D_3)
+                X2W = (((X2W + A1) + A2) + A3) + A4;
+                X0S2 = X0S2 + m23.x;                             // D_2
+                X0W2 = (((X0W2 + a[2]) + a[4]) + a[6]) + a[8];
+                X2S0 = X2S0 + m01.y;                             // D_1
+                X2W0 = (((X2W0 + a[1]) + a[3]) + a[5]) + a[7];
+            };
+            float a0[10], a1[10];
+            load(0, a1);
+            load(1, a0);
+            bins(81, a1);                                        // symbol 81: every pattern of bin fi reads D_(fi+1)
+            {
+                const float p0[3] = {a1[1], a1[2], a1[3]}, p1[3] = {a1[3], a1[4], a1[5]};
+                const float p2[3] = {a1[5], a1[6], a1[7]}, p3[3] = {a1[7], a1[8], a1[9]};
+                const float mh[3] = {m01.y, m23.x, m23.y};
+                X0S.x = X0S.x + mh[0]; X0S.y = X0S.y + mh[1]; X0S2 = X0S2 + mh[2];
+                X2S0 = X2S0 + mh[0];   X2S.x = X2S.x + mh[1]; X2S.y = X2S.y + mh[2];
+                X0W.x = (((X0W.x + p0[0]) + p1[0]) + p2[0]) + p3[0];
+                X0W.y = (((X0W.y + p0[1]) + p1[1]) + p2[1]) + p3[1];
+                X0W2  = (((X0W2  + p0[2]) + p1[2]) + p2[2]) + p3[2];
+                X2W0  = (((X2W0  + p0[0]) + p1[0]) + p2[0]) + p3[0];
+                X2W.x = (((X2W.x + p0[1]) + p1[1]) + p2[1]) + p3[1];
+                X2W.y = (((X2W.y + p0[2]) + p1[2]) + p2[2]) + p3[2];
+            }
+#pragma unroll 1
+            for (int k = 82; k < kNSymD; k += 2) {               // 82 .. 161
+                load(k + 1 - 81, a1);
+                bins(k, a0);
+                drifting(a0);
+                if (k + 2 < kNSymD) load(k + 2 - 81, a0);
+                bins(k + 1, a1);
+                drifting(a1);
+            }
+        }
+        // ---- first hypothesis (in the reference's loop order) with the strictly largest metric ------
+        float best = -1e30f;
+        int arg = -1;
+        {
+            const float r0[3] = {X0S.x / X0W.x, X0S.y / X0W.y, X0S2 / X0W2};
+            const float r1[3] = {S01.y / W01.y, S23.x / W23.x, S23.y / W23.y};
+            const float r2[3] = {X2S0 / X2W0, X2S.x / X2W.x, X2S.y / X2W.y};
+#pragma unroll
+            for (int fi = 0; fi < 3; ++fi) {
+                const int hb = fi * 32 * npat + (k0 + 10) * npat;
+                if (npat == 3) {
+                    if (r0[fi] > best) { best = r0[fi]; arg = hb; }
+                    if (r1[fi] > best) { best = r1[fi]; arg = hb + 1; }
+                    if (r2[fi] > best) { best = r2[fi]; arg = hb + 2; }
+                } else {
+                    if (r1[fi] > best) { best = r1[fi]; arg = hb; }
+                }
+            }
+        }
+        const int c = 2 * pair + half;
+        if (c >= ncand) { best = -1e30f; arg = -1; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {               // within the candidate's 32 lanes
+            const float ob = __shfl_xor(best, o);
+            const int oa = __shfl_xor(arg, o);
+            const bool take = (oa >= 0) && (arg < 0 || ob > best || (ob == best && oa < arg));
+            if (take) { best = ob; arg = oa; }
+        }
+        if ((lane & 31) == 0 && c < ncand && arg >= 0) {
+            DevCand cd = cand[(size_t)seg * kMaxCand + c];
+            const int i0 = half ? if0_b : if0_a;
+            const int f = arg / (32 * npat);
+            const int rem = arg - f * 32 * npat;
+            const int kk = rem / npat - 10;
+            const int pat = (npat == 3) ? rem % 3 : 1;
+            cd.shift = 128 * (kk + 1);
+            cd.drift = (pat == 0) ? (float)(-maxdrift) : (pat == 2 ? 1.0f : 0.0f);
+            cd.freq  = (float)((double)(i0 - 1 + f - 256) * kHalfDf);
+            cd.sync  = best;
+            cand[(size_t)seg * kMaxCand + c] = cd;
+        }
+    }
+}
 }  // namespace
 
 void launch_time_average(const float* ps, const int* seg_list, int nseg_active, int blocks, float* psavg,
@@ -421,7 +626,15 @@ void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, i
         return b;
     }();
     static const int gy = [] { const char* e = getenv("WSPR_K3_GRID_Y"); return e ? atoi(e) : 16; }();
-    if (blocks == kMaxBlocks)
+    // Full-length records of large batches take the lane-per-(candidate, lag) kernel: its single-wave workgroups
+    // pay two staging round trips each, which a launch of a few hundred candidate pairs cannot hide (1 024
+    // single-signal segments: 59 vs 46 us; 8 192 x 10 signals: 0.93 vs 1.15 ms).  WSPR_K3_KERNEL=waves / lane force one.
+    static const int forced = [] { const char* e = getenv("WSPR_K3_KERNEL"); return !e ? 0 : (e[0] == 'w' ? 1 : 2); }();
+    const bool lane_kernel = forced ? forced == 2 : nseg_active >= 1536;
+    if (blocks == kMaxBlocks && lane_kernel)
+        hipLaunchKernelGGL(coarse_sync_lane_kernel, dim3(nseg_active, gy), dim3(64), 0, st, ps, seg_list, cand, npk,
+                           maxdrift, bits);
+    else if (blocks == kMaxBlocks)
         hipLaunchKernelGGL(coarse_sync_kernel<true>, dim3(nseg_active, gy), dim3(kCsThreads), 0, st, ps, seg_list, blocks,
                            cand, npk, maxdrift, bits);
     else

@@ -107,6 +107,38 @@ def test_candidates_match_oracle(w, synth_batch, ref_iq, coarse):
             assert g.snr == o.snr                                   # ranked and reported with the host libm
 
 
+@pytest.mark.parametrize("maxdrift", [4, 0])
+def test_coarse_sync_of_a_large_batch_matches_oracle(w, synth_batch, ref_iq, maxdrift):
+    """Batches of 1 536 segments and more take the lane-per-(candidate, lag) coarse-sync kernel (one lane holds the
+    three frequency bins of its lag; amplitudes staged in two halves of 81 symbols).  The small parity batch is
+    tiled to 1 600 segments; every copy's candidates equal the oracle's: frequency, lag, drift label and sync,
+    with drift search (nine hypotheses per lag) and without (maxdrift 0: pattern 1 only)."""
+    I0 = np.concatenate([ref_iq[0][None], synth_batch[0]])
+    Q0 = np.concatenate([ref_iq[1][None], synth_batch[1]])
+    n0 = I0.shape[0]
+    reps = -(-1600 // n0)
+    I = np.tile(I0, (reps, 1)); Q = np.tile(Q0, (reps, 1))
+    nseg = I.shape[0]
+    assert nseg >= 1536
+    cands = (w.cand * (200 * nseg))()
+    npk = (C.c_int * nseg)()
+    noise = np.zeros(nseg, np.float32)
+    sm = np.zeros((nseg, 411), np.float32)
+    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, 1, maxdrift, C.addressof(cands),
+                                       C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
+    assert rc == 0
+    L = ol.lib()
+    for s0 in range(n0):
+        onpk, oc, _, _ = _oracle_cands(I0[s0], Q0[s0], 0)
+        L.orc_coarse_sync(ol.ptr(oracle_ps(I0[s0], Q0[s0])), C.c_int(347), oc, C.c_int(onpk), C.c_int(maxdrift))
+        for rep in range(reps):
+            s = rep * n0 + s0
+            assert npk[s] == onpk
+            for j in range(onpk):
+                g, o = cands[200 * s + j], oc[j]
+                assert (g.freq, g.shift, g.drift, g.sync) == (o.freq, o.shift, o.drift, o.sync), (s, j)
+
+
 # ------------------------------------------------------------------ K4 / K5
 def _both_demod(w, I, Q, freq, shift, drift, mode, lagmin=0, lagmax=0, lagstep=8, ifmin=0, ifmax=0, fstep=0.0, np_=NS):
     res = []
