@@ -83,6 +83,91 @@ void sub_runs_kernel(const SubJob* __restrict__ jobs, int njobs, PhaseTable* __r
     if (nr < 0) tb.first_run[0] = 0xffffu;
 }
 
+// The same tables with one WAVE per job (phase_runs_build_chained, phase_runs.h): up to 64 symbols are probed at
+// once, the leading ones whose 256 additions are all regular become one run each with prefix-summed
+// significands, the first that is not (a binade crossing, typically) is walked run by run; ~20 rounds per
+// signal instead of ~200-350 serial trips, and a thousand jobs are a thousand waves instead of sixteen
+// (0.34-0.43 ms of latency per launch with lane = job, during which the GPU held 16 waves).
+__global__ __launch_bounds__(64)
+void sub_runs_wave_kernel(const SubJob* __restrict__ jobs, int njobs, PhaseTable* __restrict__ tables) {
+    __shared__ float dph[kNSymD];
+    const int job = blockIdx.x, lane = threadIdx.x;
+    if (job >= njobs) return;
+    const SubJob* __restrict__ jb = jobs + job;
+    PhaseTable& tb = tables[job];
+    const float f0 = jb->f0, drift = jb->drift;
+    for (int i = lane; i < kNSymD; i += 64) {
+        const float v = dphi_of_symbol(f0, drift, i, jb->sym[i]);
+        dph[i] = v;
+        tb.dphi[i] = v;
+    }
+    __syncthreads();
+    // everything below is wave-uniform except the per-lane probe of symbol i + lane
+    float phi = 0.0f;
+    int nr = 0, i = 0;
+    bool full = false;
+    while (i < kNSymD) {
+        int32_t m = 0;
+        int e = 0, taken = 0;
+        if (phase_split(phi, &m, &e)) {
+            const int si = i + lane;
+            const bool in = si < kNSymD;
+            const PhaseSymbolStep st = phase_symbol_probe(e, (m & 1) != 0, in ? dph[si] : 0.0f);
+            const int inc = (in && st.ok) ? kSps * st.q : 0;
+            int incl = inc;                                      // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int32_t ms = m + (incl - inc);                 // significand at the start of symbol i + lane
+            const bool good = in && st.ok && phase_symbol_room(ms, st, kSps);
+            const unsigned long long bad = ~__ballot(good);
+            taken = bad ? (int)__ffsll((long long)bad) - 1 : 64;
+            if (lane < taken) {
+                tb.sym_phi[si] = phase_join(ms, e);
+                const int slot = nr + lane;
+                if (!full && slot < kPhaseMaxRuns) {
+                    tb.first_run[si] = (uint16_t)slot;
+                    tb.runs[slot] = PhaseRun{si * kSps, ms, st.q, e};
+                }
+            }
+            if (taken) {
+                const int32_t mb = taken < 64 ? __shfl(ms, taken) : __shfl(ms + inc, 63);
+                phi = phase_join(mb, e);
+                if (!full) {
+                    if (nr + taken > kPhaseMaxRuns) { nr = kPhaseMaxRuns; full = true; } else nr += taken;
+                }
+            }
+        }
+        i += taken;
+        if (taken == 64 || i >= kNSymD) continue;
+        // symbol i does not pass: walk it run by run (every lane the same walk, lane 0 stores)
+        const float d = dph[i];
+        if (lane == 0) {
+            tb.sym_phi[i] = phi;
+            if (!full) tb.first_run[i] = (uint16_t)nr;
+        }
+        int left = kSps, pos = i * kSps;
+        while (left > 0) {
+            PhaseRun r;
+            const int n = phase_next_run(phi, d, pos, left - 1, r);
+            if (nr >= kPhaseMaxRuns) full = true;
+            if (!full) {
+                if (lane == 0) tb.runs[nr] = r;
+                ++nr;
+            }
+            pos += n + 1;
+            left -= n + 1;
+        }
+        ++i;
+    }
+    if (lane == 0) {
+        tb.first_run[kNSymD] = (uint16_t)nr;
+        if (full) tb.first_run[0] = 0xffffu;
+    }
+}
+
 // One workgroup walks kSymPerWg symbols (256 samples each) of one job.  All lanes of a wave sit in the
 // same symbol, so the symbol's few runs are fetched with wave-uniform (scalar) loads and every lane
 // keeps the last one that starts at or before its sample.
@@ -346,7 +431,12 @@ void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int 
     if (njobs <= 0) return;
     float* perjob = scratch;
     PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch + (size_t)njobs * kSubPerJob);
-    hipLaunchKernelGGL(sub_runs_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, tables);
+    // WSPR_K7_RUNS=lane: the lane-per-job run builder
+    static const bool runs_lane = [] { const char* e = getenv("WSPR_K7_RUNS"); return e && e[0] == 'l'; }();
+    if (runs_lane)
+        hipLaunchKernelGGL(sub_runs_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, tables);
+    else
+        hipLaunchKernelGGL(sub_runs_wave_kernel, dim3(njobs), dim3(64), 0, st, jobs, njobs, tables);
     hipLaunchKernelGGL(sub_ref_kernel, dim3(kNSymD / kSymPerWg, njobs), dim3(256), 0, st, dI, dQ, samples, jobs, tables, perjob);
     // WSPR_K7_FIR=4: the four-outputs-per-lane kernel with the taps in LDS
     static const bool fir4 = [] { const char* e = getenv("WSPR_K7_FIR"); return e && e[0] == '4'; }();

@@ -150,6 +150,130 @@ WSPR_PR_HD int phase_runs_build(const DphiOf& dphi_of, int nsym, int sps, PhaseR
     return nr;
 }
 
+// ---- symbol-level shortcut (what lets a whole wave work on one signal) -------------------------------------
+// From a normal phase phi = m 2^(e-23) at a symbol's first sample, the symbol's `sps` additions of d are all
+// regular (constant increment q, every sum inside the binade) iff phase_symbol_probe().ok and
+// phase_symbol_room(): the symbol is then ONE run -- the run phase_next_run() would emit -- and the next symbol
+// starts at significand m + sps q with the same exponent.  Between two such breaks the symbol-start
+// significands are therefore a prefix sum of sps q_i, which lanes can form in parallel; a symbol that fails
+// either test (binade crossing, odd significand on a tie, zero or subnormal phase, huge or subnormal
+// increment) is walked with phase_next_run() as before.  The probe depends on the phase only through its
+// exponent and the parity of m, and sps q is even, so the parity is the same for every symbol of a chain.
+struct PhaseSymbolStep {
+    int32_t q;          // signed increment per sample, units of 2^(e-23)
+    int32_t fl;         // floor(|d| / 2^(e-23))
+    bool dneg, ok;
+};
+WSPR_PR_HD PhaseSymbolStep phase_symbol_probe(int e, bool m_odd, float d) {
+    PhaseSymbolStep r{0, 0, false, false};
+    const uint32_t db = pr_bits(d);
+    const int dbe = (int)((db >> 23) & 0xffu);
+    r.dneg = (db >> 31) != 0;
+    if (dbe == 0xff) return r;
+    if ((db & 0x7fffffffu) == 0) { r.ok = true; return r; }       // d = +-0: the phase never changes
+    if (dbe == 0) return r;                                        // subnormal increment: real steps
+    const int sh = (dbe - 127) - e;
+    if (sh > 0) return r;                                          // |d| / spacing >= 2^24
+    const int32_t md = (int32_t)((db & 0x7fffffu) | 0x800000u);
+    int32_t fl;
+    int frac;                                                      // as in phase_batch()
+    const int s = -sh;
+    if (s == 0) { fl = md; frac = 0; }
+    else if (s >= 25) { fl = 0; frac = 1; }
+    else {
+        fl = md >> s;
+        const int32_t rem = md & ((1 << s) - 1), half = 1 << (s - 1);
+        frac = rem == 0 ? 0 : (rem < half ? 1 : (rem == half ? 2 : 3));
+    }
+    int32_t qa;
+    if (frac == 2) {
+        if (m_odd) return r;                                       // one real step makes the significand even
+        qa = (fl & 1) ? fl + 1 : fl;
+    } else {
+        qa = fl + (frac == 3 ? 1 : 0);
+    }
+    if (qa > (1 << 16)) return r;                                  // cannot take 256 steps inside a binade anyway
+    r.q = r.dneg ? -qa : qa;
+    r.fl = fl;
+    r.ok = true;
+    return r;
+}
+// all `sps` steps from significand m (2^23 <= |m| < 2^24) are regular
+WSPR_PR_HD bool phase_symbol_room(int32_t m, const PhaseSymbolStep& s, int sps) {
+    const int32_t mag = m < 0 ? -m : m;
+    if (mag < 0x800000 || mag > 0xffffff) return false;
+    const int32_t qa = s.q < 0 ? -s.q : s.q;
+    const bool up = s.dneg == (m < 0);
+    const int32_t room = up ? (0xfffffe - s.fl) - mag : mag - (0x800001 + s.fl);
+    if (room < 0) return false;
+    if (qa == 0) return true;                                      // |d| below half a spacing: the phase is stuck
+    return (uint32_t)room / (uint32_t)qa + 1u >= (uint32_t)sps;
+}
+// float -> (m, e) of a normal phase; false for zero, subnormal and non-finite values
+WSPR_PR_HD bool phase_split(float phi, int32_t* m, int* e) {
+    const uint32_t b = pr_bits(phi);
+    const int be = (int)((b >> 23) & 0xffu);
+    if (be == 0 || be == 0xff) return false;
+    const int32_t mag = (int32_t)((b & 0x7fffffu) | 0x800000u);
+    *m = (b >> 31) ? -mag : mag;
+    *e = be - 127;
+    return true;
+}
+WSPR_PR_HD float phase_join(int32_t m, int e) {
+    const PhaseRun r{0, m, 0, e};
+    return phase_of(r, 0);
+}
+
+// The decomposition of phase_runs_build() formed chain by chain: `width` symbols are probed at once (a wave's
+// lanes on the device; a loop here), the leading ones that pass become one run each with prefix-summed
+// significands, the first that fails is walked serially.  Same tables as phase_runs_build(), bit for bit
+// (tests/test_phase_runs.py compares them); this scalar form is what the tests run and what documents
+// sub_runs_kernel's wave form.
+template <class DphiOf>
+WSPR_PR_HD int phase_runs_build_chained(const DphiOf& dphi_of, int nsym, int sps, PhaseRun* runs, int max_runs,
+                                        uint16_t* first_run, float* sym_phi, int width) {
+    float phi = 0.0f;
+    int nr = 0, i = 0;
+    bool full = false;
+    while (i < nsym) {
+        int32_t m = 0;
+        int e = 0;
+        int taken = 0;
+        if (phase_split(phi, &m, &e)) {
+            int32_t ms = m;                                        // significand at the start of symbol i + taken
+            while (taken < width && i + taken < nsym) {
+                const PhaseSymbolStep st = phase_symbol_probe(e, (m & 1) != 0, dphi_of(i + taken));
+                if (!st.ok || !phase_symbol_room(ms, st, sps)) break;
+                if (sym_phi) sym_phi[i + taken] = phase_join(ms, e);
+                if (nr >= max_runs) full = true;
+                if (!full) { first_run[i + taken] = (uint16_t)nr; runs[nr++] = PhaseRun{(i + taken) * sps, ms, st.q, e}; }
+                ms += sps * st.q;
+                ++taken;
+            }
+            if (taken) phi = phase_join(ms, e);
+        }
+        i += taken;
+        if (taken == width || i >= nsym) continue;
+        // symbol i does not pass: walk it run by run
+        const float d = dphi_of(i);
+        if (sym_phi) sym_phi[i] = phi;
+        if (!full) first_run[i] = (uint16_t)nr;
+        int left = sps, pos = i * sps;
+        while (left > 0) {
+            PhaseRun r;
+            const int n = phase_next_run(phi, d, pos, left - 1, r);
+            if (nr >= max_runs) full = true;
+            if (!full) runs[nr++] = r;
+            pos += n + 1;
+            left -= n + 1;
+        }
+        ++i;
+    }
+    if (full) return -1;
+    first_run[nsym] = (uint16_t)nr;
+    return nr;
+}
+
 // fallback for a walk whose runs did not fit: step from the symbol's first phase
 WSPR_PR_HD float phase_from_symbol(float sym_phi, float d, int j) {
     float phi = sym_phi;

@@ -29,3 +29,26 @@ extern "C" int phase_runs_check(const float* dphi, int nsym, int sps_log2, long*
     *mismatches = bad;
     return nr;
 }
+
+// The chained form (phase_runs_build_chained, what sub_runs_kernel does with a wave) must produce the SAME tables as
+// the serial builder: returns the number of differing table entries (runs, first_run, sym_phi), -1 if the run
+// counts differ.
+extern "C" long phase_runs_chained_diff(const float* dphi, int nsym, int sps_log2, int max_runs, int width) {
+    const int sps = 1 << sps_log2;
+    if (max_runs <= 0) max_runs = wspr::kPhaseMaxRuns;
+    std::vector<wspr::PhaseRun> ra(max_runs), rb(max_runs);
+    std::vector<uint16_t> fa(nsym + 1), fb(nsym + 1);
+    std::vector<float> pa(nsym), pb(nsym);
+    const int na = wspr::phase_runs_build([&](int i) { return dphi[i]; }, nsym, sps, ra.data(), max_runs, fa.data(), pa.data());
+    const int nb = wspr::phase_runs_build_chained([&](int i) { return dphi[i]; }, nsym, sps, rb.data(), max_runs, fb.data(),
+                                                  pb.data(), width);
+    if (na != nb) return -1;
+    long bad = 0;
+    for (int i = 0; i < nsym; ++i) bad += wspr::pr_bits(pa[i]) != wspr::pr_bits(pb[i]);
+    if (na >= 0) {
+        for (int i = 0; i <= nsym; ++i) bad += fa[i] != fb[i];
+        for (int r = 0; r < na; ++r)
+            bad += ra[r].start != rb[r].start || ra[r].m0 != rb[r].m0 || ra[r].q != rb[r].q || ra[r].e != rb[r].e;
+    }
+    return bad;
+}

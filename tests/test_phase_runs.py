@@ -19,6 +19,8 @@ def pr(tmp_path_factory):
                     os.path.join(ROOT, "tests", "helpers", "phase_runs_check.cpp")], check=True)
     L = C.CDLL(str(so))
     L.phase_runs_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.phase_runs_chained_diff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.phase_runs_chained_diff.restype = C.c_long
     return L
 
 
@@ -26,6 +28,9 @@ def _check(pr, dphi, sps_log2=8, max_runs=0):
     d = np.ascontiguousarray(dphi, np.float32)
     bad = C.c_long(-1)
     nr = pr.phase_runs_check(d.ctypes.data, d.size, sps_log2, C.addressof(bad), None, max_runs)
+    # the chained construction (a wave of the GPU kernel probes 64 symbols at once) gives the same tables
+    for width in (64, 5):
+        assert pr.phase_runs_chained_diff(d.ctypes.data, d.size, sps_log2, max_runs, width) == 0, (width, d[:4])
     return nr, bad.value
 
 
