@@ -281,6 +281,7 @@ def main():
         gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
         if config == 5:                                  # the decimator's output rows, one set per lane
             IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
+            torch.cuda.synchronize()                     # raw pointers from here on (stream contract of the library)
 
         def decode_on(k):
             if config == 5:

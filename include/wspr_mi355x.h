@@ -84,7 +84,10 @@ int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t se
 
 /* Same, with the IQ already resident in HBM (device pointers, same layout).
  * The input is copied to a working buffer and left untouched.  This is the
- * entry point bench.py times. */
+ * entry point bench.py times.
+ * Stream contract (every entry point that takes device pointers): the library works on streams of its own
+ * and does not know the caller's; the buffers must be COMPLETE when the call is made (synchronise the stream
+ * or event that produces them first), and everything the call writes is complete when it returns. */
 int wspr_decode_batch_device(const void *d_idat, const void *d_qdat, int nseg, int samples,
                              size_t seg_stride, struct decoder_options options,
                              struct decoder_results *decodes, int max_results, int *n_results);

@@ -152,6 +152,16 @@ def wspr_decode_batch(I, Q, options=None, max_results=50):
     return [[out[s * max_results + i] for i in range(nres[s])] for s in range(nseg)]
 
 
+def sync_torch():
+    """The library runs on streams of its own (include/wspr_mi355x.h, stream contract): whatever torch still has
+    in flight for a tensor -- the index or fill kernel that built it a moment ago -- must have landed before a
+    device pointer to it is handed over.  Call this between the torch code and a raw-pointer entry point."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
+
+
 class BatchDecoder:
     """Decodes segments already resident in HBM (torch tensors or raw device pointers)."""
 
@@ -171,6 +181,7 @@ class BatchDecoder:
     def decode(self, ti, tq):
         """ti, tq: contiguous float32 CUDA tensors [nseg, samples]."""
         assert ti.is_cuda and tq.is_cuda and ti.is_contiguous() and tq.is_contiguous()
+        sync_torch()
         return self.decode_ptr(ti.data_ptr(), tq.data_ptr(), ti.shape[1], ti.stride(0))
 
     def spots(self, s):

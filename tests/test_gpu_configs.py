@@ -106,6 +106,7 @@ def test_config5_full_size_raw_segments_through_k0_and_decode(env):
     stride = int(w.lib().wspr_iq_stride())
     dI = torch.zeros(nseg, stride, device=dev)
     dQ = torch.zeros(nseg, stride, device=dev)
+    w.sync_torch()                                 # raw pointers next: torch's fills and the cat have to be done
     assert w.lib().wspr_decimate_u8_batch_device(raw.data_ptr(), RAW, nseg, dI.data_ptr(), dQ.data_ptr(), 1) == 0
     dec = w.BatchDecoder(nseg, 32)
     dec.decode_ptr(dI.data_ptr(), dQ.data_ptr(), NS, stride)      # working copies are taken; dI/dQ stay

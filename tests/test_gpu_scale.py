@@ -135,6 +135,7 @@ def test_batched_device_decimator_equals_oracle(env):
     d_raw = torch.from_numpy(np.stack(rows)).to(dev)
     stride = int(w.lib().wspr_iq_stride())
     dI = torch.zeros(nseg, stride, device=dev); dQ = torch.zeros(nseg, stride, device=dev)
+    w.sync_torch()                                 # raw pointers next
     for norm in (0, 1):
         assert w.lib().wspr_decimate_u8_batch_device(d_raw.data_ptr(), 2 * nsamp, nseg, dI.data_ptr(), dQ.data_ptr(), norm) == 0
         gi, gq = dI.cpu().numpy(), dQ.cpu().numpy()
@@ -176,6 +177,7 @@ def test_many_receivers_streaming_decimator_equals_oracle(env):
     for c in range(nchunks):
         d_raw = torch.from_numpy(np.stack([st[c * nb:(c + 1) * nb] for st in streams])).to(dev)
         nout = (C.c_int * nrx)()
+        w.sync_torch()
         assert w.lib().wspr_decimate_u8_batch_device_stateful(
             C.c_void_p(d_raw.data_ptr()), C.c_size_t(nb), nrx, C.c_void_p(states.data_ptr()), C.c_void_p(dI.data_ptr()),
             C.c_void_p(dQ.data_ptr()), nout) == 0

@@ -13,6 +13,7 @@ L = w.lib()
 stride = int(L.wspr_iq_stride())
 I = torch.zeros(nseg, stride, device=dev); Q = torch.zeros_like(I)
 ms = (C.c_double * 1)()
+torch.cuda.synchronize()
 for rep in range(3):
     L.wspr_bench_decimate(raw.data_ptr(), RAW, nseg, I.data_ptr(), Q.data_ptr(), 20, C.addressof(ms))
     k0 = ms[0]
