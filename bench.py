@@ -373,6 +373,10 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k1,
                 "bytes_per_launch": K1_BYTES * nseg,
+                # what the kernel really moves (PMC): the fused form does not send the 106 bin rows that only the
+                # time average needed to HBM, so its traffic is BELOW the algorithmic figure of SURVEY 8(d)
+                "traffic_GBs": (traffic / (k1 * 1e-3) / 1e9) if traffic else None,
+                "traffic_frac_of_peak": (traffic / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
                                    "wall_ms": ms[4],
                                    "bytes_per_launch": STAGE_BYTES * nseg,

@@ -336,7 +336,11 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
         }
         __syncthreads();                                               // the group's tile is complete
         const int nt = min(kWgTimes, blocks - t0);
-        for (int e = threadIdx.x; e < kPsBins * kParts; e += 256) {
+        // Only the rows the coarse sync can reach go to HBM: a candidate lies within +-110 Hz (wsprd.c:600-606), i.e.
+        // if0 in [106, 406], and reads bins if0 - 6 .. if0 + 4 = 100 .. 410; the 106 rows outside were needed
+        // for the time average alone, which this kernel forms itself.
+        constexpr int kRowLo = 100 - kPsBin0, kRowHi = 410 - kPsBin0;
+        for (int e = threadIdx.x + kRowLo * kParts; e < (kRowHi + 1) * kParts; e += 256) {
             const int b = e / kParts, part = e - b * kParts;
             const int tl = 4 * part;
             if (tl >= nt) continue;
