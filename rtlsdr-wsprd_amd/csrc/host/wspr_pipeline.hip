@@ -393,7 +393,7 @@ static void fft_and_average(const float* dI, const float* dQ, const int* d_segli
         ev->push_back(e);
     };
     static const int fused_cfg = [] { const char* e = getenv("WSPR_K1_FUSED"); return e ? atoi(e) : -1; }();
-    const bool fused = fused_cfg < 0 ? nactive >= 512 : fused_cfg != 0;
+    const bool fused = fused_cfg < 0 ? nactive >= 256 : fused_cfg != 0;
     mark();
     if (fused) launch_fft_bank_avg(dI, dQ, d_seglist, nactive, samples, ps, psavg, tab, st);
     else launch_fft_bank(dI, dQ, d_seglist, nactive, samples, ps, tab, st);
