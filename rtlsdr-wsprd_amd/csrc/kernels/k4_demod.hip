@@ -11,6 +11,16 @@
 // sums (sync metric, soft-symbol normalisation) are formed by one lane in symbol
 // order.  Phasor seeds come from glibc-exact sinf/cosf (glibc_sincosf.h).
 // Bound: fp32 VALU (AI > 100 flop/B); no MFMA (separately rounded mul/add chains).
+//
+// Kernels in this file, by the stage they serve (every one performs demod_kernel's operations per accumulator):
+//   general               demod_kernel                 any mode, any drift; exported sync_and_demodulate()
+//   mode 0, no drift      demod_lag3_kernel            three symbols per lane, table through the scalar cache
+//   mode 0, drift         demod_drift_kernel           three lags per lane, per-symbol tables in an LDS ring
+//   mode 0 (quick mode), ladder rungs (mode 2, 43 lags)
+//                         phasor_table_kernel + demod_tile_kernel<STEP, shared> + demod_metric_kernel
+//   mode 1 + rung 0, no drift   phasor_freq_kernel + freq_scalar_kernel (freq_tile_kernel: tables in LDS) + freq_metric_kernel
+//   mode 1 + rung 0, drift      freq_drift_kernel + freq_metric_kernel
+//   epilogues             pick_lag_kernel, pick_freq_kernel;  calibration: calib_valu_kernel
 #include "wspr_device.h"
 #include "glibc_sincosf.h"
 #include <cstdlib>
