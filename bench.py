@@ -204,7 +204,7 @@ def main():
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight (default 2 when the rank has >= 6 CPUs, else 1): step k+1 starts "
+                    help="batches in flight (default: 4 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
     args = ap.parse_args()
 
@@ -231,7 +231,8 @@ def main():
     # crowded band (configs[2]): the Fano attempts run on the device (library default for such batches), the host
     # only keeps books, and four batches in flight cover the device round trips of a wave (25.5 / 25.9 / 27.2 k
     # segments/s with 2 / 3 / 4 in flight; also with 2 host threads); otherwise two if the rank has the CPUs
-    inflight = args.inflight if args.inflight else (4 if args.config == 3 else (2 if cpus_here >= 6 else 1))
+    inflight = args.inflight if args.inflight else (4 if args.config == 3 else
+                                                   (3 if args.config == 2 and cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
     inflight = max(1, min(inflight, 4))
     from concurrent.futures import ThreadPoolExecutor
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
