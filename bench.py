@@ -370,7 +370,8 @@ def main():
                 if per_seg:
                     traffic, traffic_src = per_seg * nseg, "profiles/" + name
                     break
-        roof = {"bound": "hbm", "kernel": "fft_bank_kernel (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
+        roof = {"bound": "hbm", "kernel": "fft_bank_avg_kernel<4> (K1 fused with the time average)" if nseg >= 256
+                else "fft_bank_kernel<4> (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k1,
                 "bytes_per_launch": K1_BYTES * nseg,
