@@ -466,10 +466,23 @@ def main():
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
-        print(json.dumps(out))
+    line = json.dumps(out) if rank == 0 else None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: RCCL writes its version banner and warnings through C stdio
+    # (NCCL_DEBUG=VERSION is exported on the GPU boxes), which, on a pipe, is only flushed at exit -- i.e. after a
+    # line printed earlier from Python.  Every rank flushes C stdio now; rank 0 prints once the others have had
+    # the time to leave.
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
