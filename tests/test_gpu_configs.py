@@ -280,3 +280,35 @@ def test_receiver_session_two_minute_flow(env):
     assert L.wspr_session_decode(s, 1, C.addressof(out), C.byref(n)) == 0 and n.value == 0
     O.orc_decim_free(C.c_void_p(ost))
     L.wspr_session_destroy(s)
+
+
+# ------------------------------------------------------------------ calibration hooks behind the rooflines
+def test_calibration_hooks_report_plausible_ceilings(env):
+    """The three ceilings bench.py prints beside the rooflines come from kernels of the library itself: a stream copy
+    (4 and 16 bytes per lane), a read-only stream with K0's access pattern, and register-only chains of separately
+    rounded packed multiplies and adds.  They must run and land where an MI355X can be: between a fifth of the
+    peak and the peak."""
+    import time
+    torch, bench, w, dev = env
+    L = w.lib()
+    n = 1 << 26
+    src = torch.empty(n, device=dev, dtype=torch.float32).normal_(); dst = torch.empty_like(src)
+    w.sync_torch()
+    for fn in (L.wspr_calib_copy, L.wspr_calib_copy16):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert fn(src.data_ptr(), dst.data_ptr(), n, 2) == 0
+        t0 = time.perf_counter()
+        assert fn(src.data_ptr(), dst.data_ptr(), n, 10) == 0
+        gbs = 10 * 8.0 * n / (time.perf_counter() - t0) / 1e9
+        assert 1500.0 < gbs < 8000.0, gbs
+        assert torch.equal(src, dst)
+    raw = torch.randint(1, 256, (4, bench.RAW_BYTES), device=dev, dtype=torch.uint8)
+    w.sync_torch()
+    ms = (C.c_double * 1)()
+    assert L.wspr_calib_read(raw.data_ptr(), bench.RAW_BYTES, 4, 5, C.addressof(ms)) >= 0
+    read_gbs = 4 * bench.RAW_BYTES / (ms[0] * 1e-3) / 1e9
+    assert 2000.0 < read_gbs < 8000.0, read_gbs
+    tf = C.c_double(0.0)
+    L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
+    assert L.wspr_calib_valu(10, C.addressof(tf)) == 0
+    assert 30.0 < tf.value <= 78.7, tf.value                  # the no-FMA vector bound is 78.6 TF/s
