@@ -23,6 +23,24 @@ def shard_range(nseg_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def in_rank_order(fn):
+    """Runs fn() on rank 0, then on rank 1, ... with a barrier between the turns, and returns this rank's result.
+
+    For options.usehashtable = 1: the hash memory that resolves type-3 "<call>" messages lives in
+    hashtable.txt of the working directory, read before and written after every decode (wsprd.c:481-494, 842-852),
+    so the result depends on the ORDER of the segments.  Ranks that share the working directory and take their
+    turns in rank order over contiguous shards (shard_range) see the segments in global index order -- exactly what
+    one reference process walking all of them would produce.  There is nothing to parallelise in that mode; this
+    keeps the sharded driver correct for it."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out = None
+    for r in range(world):
+        if r == rank:
+            out = fn()
+        dist.barrier()
+    return out
+
+
 def _dev():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 

@@ -100,3 +100,95 @@ def _run_world2(product):
     flat = [m for r in msgs for m in r]
     assert flat == single
     assert sum(map(sum, counts)) == sum(cnt) and sum(cnt) >= NSEG - 1
+
+
+# ---- usehashtable across ranks: the order-dependent hash memory -------------------------------
+_HT_MSGS = [["PJ4/K1ABC 37"], ["W1AW FN31 10"], ["<PJ4/K1ABC> FK52UD 37", "W1AW FN31 10"], ["<PJ4/K1ABC> FK52UD 37"]]
+
+
+def _ht_segments():
+    import oracle_lib as ol
+    import synth
+    symf = lambda m: ol.channel_symbols(m)[1]
+    segs = []
+    for k, msgs in enumerate(_HT_MSGS):
+        rng = np.random.default_rng(7100 + k)
+        sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+        I = rng.normal(0, sigma, synth.NS); Q = rng.normal(0, sigma, synth.NS)
+        for j, m in enumerate(msgs):
+            si, sq = synth.tone_signal(symf(m), -40.0 + 60.0 * j, 2.0, 10.0 ** (-8.0 / 20.0))
+            I += si; Q += sq
+        segs.append(synth.normalise(I.astype(np.float32), Q.astype(np.float32)))
+    return segs
+
+
+def _ht_decode(segs, lo, hi, product):
+    """Segments lo..hi-1 one after the other with usehashtable = 1 (hashtable.txt in the working directory)."""
+    import oracle_lib as ol
+    import rtlsdr_wsprd_amd as w
+    out = []
+    for s in range(lo, hi):
+        if product:
+            po = w.default_options(); po.usehashtable = 1
+            spots, _, _ = w.wspr_decode(segs[s][0], segs[s][1], 45000, po)
+        else:
+            o = ol.default_options(); o.usehashtable = 1
+            spots, _, _ = ol.decode(segs[s][0], segs[s][1], 45000, o)
+        out.append(sorted(x.message.split(b"\0")[0].decode() for x in spots))
+    return out
+
+
+def _ht_worker(rank, world, port, q, workdir, product):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.chdir(workdir)                                            # the ranks share hashtable.txt
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_wsprd_amd import dist as wd
+    segs = _ht_segments()
+    lo, hi = wd.shard_range(len(segs), rank, world)
+    mine = wd.in_rank_order(lambda: _ht_decode(segs, lo, hi, product))
+    allm = [None] * world
+    dist.all_gather_object(allm, mine)
+    if rank == 0:
+        q.put([m for part in allm for m in part])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_hashtable_world2(tmp_path, product):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shared = tmp_path / "ranks"; shared.mkdir()
+    port = 31500 + os.getpid() % 2000 + (11 if product else 0)
+    procs = [ctx.Process(target=_ht_worker, args=(r, 2, port, q, str(shared), product)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # one process walking the four segments in order, in a directory of its own (the oracle: the checker)
+    alone = tmp_path / "alone"; alone.mkdir()
+    cwd = os.getcwd()
+    try:
+        os.chdir(alone)
+        ref = _ht_decode(_ht_segments(), 0, len(_HT_MSGS), False)
+        ref_file = open("hashtable.txt").read()
+    finally:
+        os.chdir(cwd)
+    assert got == ref
+    assert open(shared / "hashtable.txt").read() == ref_file
+    # the hashed call of the last two segments (rank 1's shard) is resolved by what rank 0 heard
+    assert got[0] == ["PJ4/K1ABC 37"] and "<PJ4/K1ABC> FK52UD 37" in got[2] and got[3] == ["<PJ4/K1ABC> FK52UD 37"]
+
+
+def test_world2_hashtable_segments_in_rank_order(tmp_path):
+    """usehashtable = 1 over two ranks (gloo, the oracle decoding): with in_rank_order() over contiguous shards the
+    ranks produce the spots and the hashtable.txt of ONE process walking all segments in index order."""
+    _run_hashtable_world2(tmp_path, product=False)
+
+
+@pytest.mark.gpu
+def test_world2_hashtable_segments_in_rank_order_through_the_product(tmp_path):
+    _run_hashtable_world2(tmp_path, product=True)
