@@ -155,7 +155,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
+        nvalid, decscratch, tabs, pw, pwfreq, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
     int sub_flip = 0;
     bool dev_fano = false;           // this batch: Fano attempts on the device (see fano_device_mode())
@@ -865,9 +865,11 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
         {
             float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
             float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
+            // the frequency scan reads its centre hypothesis out of the lag scan's block (d_pw), so it writes elsewhere
+            float* d_pwf = static_cast<float*>(c.pwfreq.need((size_t)nw * 5 * kNSymD * 16));
             launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, lagstep,
-                                            minsync1, c.t_jitter.as<int>(), d_tabs1, d_pw, d_scr, d_sync0, d_sym0,
-                                            d_rms0, c.tab, c.stream);
+                                            minsync1, c.t_jitter.as<int>(), d_tabs1, d_pwf, d_scr, d_sync0, d_sym0,
+                                            d_rms0, c.tab, c.stream, d_pw, nlag0);
         }
         // device-Fano mode: the soft symbols stay in HBM, only items / sync / rms come down
         HIP_OK(hipMemcpyAsync(h_down, d_blk, c.dev_fano ? o_sym : down_bytes, hipMemcpyDeviceToHost, c.stream));
@@ -1320,6 +1322,7 @@ int Context::bench_valu(int nseg, int samples, int iters, double* ms) {
     unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need((size_t)nw * kMaxLags * kNSymD));
     float* d_rms = static_cast<float*>(c.rmsbuf.need((size_t)nw * kMaxLags * 4));
     float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
+    float* d_pwf = static_cast<float*>(c.pwfreq.need((size_t)nw * 5 * kNSymD * 16));
     SubJob* dj = static_cast<SubJob*>(c.jobs.need((size_t)nw * sizeof(SubJob)));
     float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(nw) * 4));
     HIP_OK(hipMemcpyAsync(d_items, items.data(), (size_t)nw * sizeof(FineState), hipMemcpyHostToDevice, c.stream));
@@ -1338,7 +1341,8 @@ int Context::bench_valu(int nseg, int samples, int iters, double* ms) {
         HIP_OK(hipEventRecord(e[1], c.stream));
         launch_pick_lag(d_items, nw, d_sync, 33, 8, c.stream);
         launch_freq_scan_and_first_rung(wi, wq, samples, d_items, d_lists, n_shared, d_lists + nw, n_own, 8, 0.10f,
-                                        c.t_jitter.as<int>(), d_tabs, d_pw, d_scr, d_sync, d_sym, d_rms, c.tab, c.stream);
+                                        c.t_jitter.as<int>(), d_tabs, d_pwf, d_scr, d_sync, d_sym, d_rms, c.tab, c.stream,
+                                        d_pw, 33);
         HIP_OK(hipEventRecord(e[2], c.stream));
         launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), samples, dj, nw, scratch, c.tab, c.stream);
         HIP_OK(hipEventRecord(e[3], c.stream));

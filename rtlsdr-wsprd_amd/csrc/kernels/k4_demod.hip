@@ -691,6 +691,19 @@ void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restr
 // comes out of the same pass.  lane = (symbol, frequency).
 constexpr int kNFreq = 5;
 
+// The centre hypothesis of the frequency scan (ifreq = 0) is the lag scan's winner over again: mode 0 left
+// *freq at freq_coarse and set *shift to the best lag of its grid (wsprd.c:709-719), so mode 1 at f0 = *freq + 0
+// and lag = *shift (:721-726) repeats, operation for operation, the sums whose tone amplitudes the lag scan
+// already wrote for that lag.  Returns the lag's index in the lag-scan block, or -1 when the state is not a grid
+// point of that scan (no lag won: NaN metrics) or no block is given.
+__device__ __forceinline__ int centre_from_lag_scan(const FineState& st, int nlag, int lagstep) {
+    if (nlag <= 0 || !(st.freq == st.freq_coarse)) return -1;
+    const int d = st.shift - (st.shift_coarse - 128);
+    if (d < 0 || d % lagstep != 0) return -1;
+    const int m = d / lagstep;
+    return m < nlag ? m : -1;
+}
+
 __global__ __launch_bounds__(64)
 void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin,
                         float fstep, float* __restrict__ tabs) {
@@ -787,15 +800,19 @@ constexpr int kFqPerThread = (kNSymD * kFsChunk + kFqThreads - 1) / kFqThreads; 
 __global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                         const FineState* __restrict__ items, const int* __restrict__ item_list,
-                        const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+                        const float* __restrict__ tabs, float4* __restrict__ pw_out,
+                        const float4* __restrict__ pw_lag, int nlag, int lagstep) {
     __shared__ float2 tile[kNSymD][kFsChunk + 1];
     const int slot = blockIdx.x, tid = threadIdx.x;
-    const FineState st = items[item_list[slot]];
+    const int item = item_list[slot];
+    const FineState st = items[item];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = wave / 3, sym = (wave - 3 * f) * 64 + (tid & 63);
-    const bool working = sym < kNSymD;
+    // the centre hypothesis' three waves only help staging when the lag scan holds its amplitudes
+    const int m_centre = (f == kNFreq / 2) ? centre_from_lag_scan(st, pw_lag ? nlag : 0, lagstep) : -1;
+    const bool working = sym < kNSymD && m_centre < 0;
     const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps);
 
     float2 nxt[kFqPerThread];
@@ -829,6 +846,7 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
         }
     }
     if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
+    else if (sym < kNSymD) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
 }
 
 // The same scan for a DRIFTING candidate: every (hypothesis, symbol) has its own four tone phasors and each
@@ -840,14 +858,17 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
 __global__ __launch_bounds__(kFsThreads) __attribute__((amdgpu_waves_per_eu(7, 8)))     // <= 72 VGPRs: two workgroups per CU
 void freq_drift_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin, float fstep,
-                       float4* __restrict__ pw_out) {
+                       float4* __restrict__ pw_out, const float4* __restrict__ pw_lag, int nlag, int lagstep) {
     __shared__ float2 tile[kNSymD][kFsChunk + 1];
     const int slot = blockIdx.x, tid = threadIdx.x;
-    const FineState st = items[item_list[slot]];
+    const int item = item_list[slot];
+    const FineState st = items[item];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int f = tid / kNSymD, sym = tid - f * kNSymD;
-    const bool working = f < kNFreq;
+    // (a thread of the centre hypothesis copies the lag scan's amplitudes when they are its own: see centre_from_lag_scan)
+    const int m_centre = (f == kNFreq / 2) ? centre_from_lag_scan(st, pw_lag ? nlag : 0, lagstep) : -1;
+    const bool working = f < kNFreq && m_centre < 0;
 
     float2 nxt[kFsPerThread];
     auto fetch = [&](int c) {
@@ -897,6 +918,7 @@ void freq_drift_kernel(const float* __restrict__ dI, const float* __restrict__ d
         }
     }
     if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
+    else if (f < kNFreq) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
 }
 
 // one wave per candidate: lanes 0..4 fold one frequency hypothesis each (162 symbols in
@@ -1034,7 +1056,11 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                                      const int* list_shared, int n_shared, const int* list_own, int n_own,
                                      int lagstep, float minsync1, const int* jitter0, float* tabs, float* pw,
                                      float* scratch_sync, float* sync_out, unsigned char* sym_out,
-                                     float* rms_out, const DeviceTables& t, hipStream_t st) {
+                                     float* rms_out, const DeviceTables& t, hipStream_t st,
+                                     const float* pw_lag, int nlag_lag) {
+    // pw_lag (optional): the lag scan's amplitude block [item][nlag_lag][162] of the SAME items, still intact --
+    // the centre hypothesis is read from it instead of being summed again; pw must then be a different buffer
+    const float4* pl = reinterpret_cast<const float4*>(pw_lag);
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
         const size_t fs_lds = kNFreq * 2 * kSps * sizeof(float4) + (size_t)kNSymD * (kFsChunk + 1) * sizeof(float2);   // 83 KB
@@ -1042,7 +1068,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
         static const bool lds_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return e && e[0] == 'l'; }();
         if (!lds_tab)
             hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
-                               list_shared, tabs, reinterpret_cast<float4*>(pw));
+                               list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_lag, lagstep);
         else {
             lds_opt_in(reinterpret_cast<const void*>(&freq_tile_kernel), fs_lds, fs_opted);
             hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
@@ -1058,7 +1084,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
             // pw rows of the drifting candidates follow those of the drift-free ones
             float4* pw_own = reinterpret_cast<float4*>(pw) + (size_t)n_shared * kNFreq * kNSymD;
             hipLaunchKernelGGL(freq_drift_kernel, dim3(n_own), dim3(kFsThreads), 0, st, dI, dQ, samples, items, list_own,
-                               -2, 0.1f, pw_own);
+                               -2, 0.1f, pw_own, pl, nlag_lag, lagstep);
             hipLaunchKernelGGL(freq_metric_kernel, dim3(n_own), dim3(64), 0, st, pw_own, items, list_own, n_own, -2, 0.1f,
                                minsync1, sync_out, sym_out, rms_out, t.sync);
             return;

@@ -133,7 +133,8 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                                      const int* list_shared, int n_shared, const int* list_own, int n_own,
                                      int lagstep, float minsync1, const int* jitter0, float* tabs, float* pw,
                                      float* scratch_sync, float* sync_out, unsigned char* sym_out,
-                                     float* rms_out, const DeviceTables& t, hipStream_t st);
+                                     float* rms_out, const DeviceTables& t, hipStream_t st,
+                                     const float* pw_lag = nullptr, int nlag_lag = 0);
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st);
 void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nfreq, int ifmin,
                       float fstep, hipStream_t st);
