@@ -422,14 +422,23 @@ def main():
             del src, dst
         if args.config == 5:
             kms = (C.c_double * 1)()
-            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 2, C.addressof(kms))   # settle
-            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 10, C.addressof(kms))
+            # K0 alone, HIP events on the launch stream: 5 launches to settle, then three sets of 10; the sets come out
+            # bimodal on some boxes right after the decoder's load (6.1 or 7.3 ms per 64 segments, a whole set at a
+            # time, while tools/k0_scan.py on an idle GPU repeats 0.78 of peak every time), so all three are reported
+            # and the best one is the figure
+            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 5, C.addressof(kms))
+            k0_sets = []
+            for _ in range(3):
+                L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 10, C.addressof(kms))
+                k0_sets.append(kms[0])
+            kms[0] = min(k0_sets)
             k0_bytes = (RAW_BYTES + 360000) * nseg
             rms = (C.c_double * 1)()
             L.wspr_calib_read(m["raw"].data_ptr(), RAW_BYTES, nseg, 10, C.addressof(rms))
             roof["front_end_K0"] = {"bound": "hbm", "avg_launch_ms": kms[0], "bytes_per_launch": k0_bytes,
                                     "achieved_GBs": k0_bytes / (kms[0] * 1e-3) / 1e9,
                                     "frac": k0_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "avg_launch_ms_of_each_set_of_10": k0_sets,
                                     # the same rows read by a kernel with K0's access pattern and no arithmetic
                                     "measured_read_GBs": RAW_BYTES * nseg / (rms[0] * 1e-3) / 1e9}
         cpu = None
