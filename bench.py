@@ -185,6 +185,30 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
                       "segments/s" % (n, cores, os.cpu_count() or 0, 1.0 / one)}, res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: re-executes this script as N ranks of ONE node under
+    torch.distributed.run (one rank per GPU, RCCL over xGMI, rendezvous on 127.0.0.1), each rank with its share of
+    the host's CPUs.  Fails loudly if the node has fewer than N GPUs."""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit("bench.py: --gpus %d but only %d HIP device(s) visible on this node" % (n, have))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on these hosts
+    env["WSPR_BENCH_SPAWNED"] = "1"
+    if n == 1:
+        env["WSPR_BENCH_FORCE_DIST"] = "1"               # --spawn on a 1-GPU box: still the RCCL code path
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,9 +230,17 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight (default: 4 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
+    ap.add_argument("--spawn", action="store_true",
+                    help="take the launcher path even for --gpus 1 (one rank under torch.distributed.run with the RCCL "
+                         "process group, broadcast and gather): how the multi-GPU entry is exercised on a 1-GPU box")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        launch_ranks(args.gpus)                          # does not return: re-executes under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N spawns them "
+                 "itself; under torch.distributed.run pass --nproc-per-node N)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     # host Fano pool: share the host's cores between the ranks of this node
     os.environ.setdefault("WSPR_HOST_THREADS", str(max(2, usable_cpus() // max(1, world))))
@@ -355,6 +387,30 @@ def main():
     nseg = args.segments or {2: 1024, 3: 8192, 5: 64}[args.config]
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
 
+    fanout = None
+    if use_dist and args.config != 5:
+        # ---- real-input fan-out, untimed (the reference's callers hold the IQ in ONE place,
+        # rtlsdr_wsprd.c:316, :689): rank 0 scatters rows of ITS batch over RCCL (grouped send/recv of 360 000 B
+        # per segment), every rank decodes the rows it received, the records come back in global order and
+        # must equal what rank 0 decoded for the same segments in the timed steps.
+        per = 4
+        ntot = min(nseg, per * world)
+
+        def decode_rows(mi, mq, o):
+            d = w.BatchDecoder(mi.shape[0], max_results=16, options=o)
+            if mi.shape[0]:
+                d.decode(mi.contiguous(), mq.contiguous())
+            return d.out, d.nres
+        res = wd.decode_from_root(m["I"][:ntot, :NS] if rank == 0 else None, m["Q"][:ntot, :NS] if rank == 0 else None,
+                                  ntot, NS, opt, decode_rows, max_results=16, record_size=rec, root=0)
+        if rank == 0:
+            cnt, recs = res
+            back = [sorted(bytes(recs[s, k * rec + 28:k * rec + 51]).split(b"\0")[0].decode() for k in range(cnt[s]))
+                    for s in range(ntot)]
+            same = sum(1 for s in range(ntot) if back[s] == sorted(m["got"][s]))
+            fanout = {"segments_scattered_from_rank0": ntot, "bytes_per_segment": 2 * 4 * NS,
+                      "equal_to_rank0_own_decode": "%d/%d" % (same, ntot), "over": "rccl send/recv (grouped)"}
+
     if rank == 0:
         I, Q = m["I"], m["Q"]
         # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
@@ -466,6 +522,8 @@ def main():
                                    "defaults (npasses 2, subtraction on, quickmode off)",
                        "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0",
                        "gathered_over": "rccl" if use_dist else "none (one process)",
+                       "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("WSPR_BENCH_SPAWNED")
+                       else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
                        "batches_in_flight": inflight, "untimed_steps": m["untimed"]},
             "steps_requested": args.steps, "seconds_timed": m["elapsed"], "first_try": m["first_try"],
             "decoded_ok": m["decoded_ok"], "false_decodes": m["false_decodes"], "spots_total": m["spots_total"],
@@ -473,7 +531,7 @@ def main():
                                                          "step; counts: sum over its slots"),
             "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
-            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "fanout_check": fanout,
         }
     line = json.dumps(out) if rank == 0 else None
     if use_dist:

@@ -92,6 +92,20 @@ int wspr_decode_batch_device(const void *d_idat, const void *d_qdat, int nseg, i
                              size_t seg_stride, struct decoder_options options,
                              struct decoder_results *decodes, int max_results, int *n_results);
 
+/* Node-level form (SURVEY §8e "one host process, 8 devices"): the nseg host segments are split into contiguous
+ * blocks by wspr_shard_range() over `ndevices` HIP devices (0 = every visible device; more than are visible is an
+ * error), one host thread per device, each block decoded by wspr_decode_batch() on its device straight into the
+ * caller's arrays.  The segments are independent (hashtab/loctab are locals of wspr_decode, wsprd.c:478-479), so no
+ * collective is involved and the result equals wspr_decode_batch() on one device.  The host's CPUs are shared
+ * between the devices (pools of contexts created from then on are sized for a 1/ndevices share).  With
+ * options.usehashtable the segments are ordered and the call is wspr_decode_batch() on the current device. */
+int wspr_decode_batch_node(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
+                           struct decoder_options options, struct decoder_results *decodes,
+                           int max_results, int *n_results, int ndevices);
+/* The partitioning rule of the node-level call and of the multi-process driver (rtlsdr-wsprd_amd/dist.py
+ * shard_range): shard k of n owns segments [*lo, *hi), the first nseg % n shards one segment more. */
+void wspr_shard_range(int nseg, int shard, int nshards, int *lo, int *hi);
+
 /* Front end, replaces the static rtlsdr_callback() + decoder() normalisation
  * (reference rtlsdr_wsprd.c:126-244, :284-305).  iq = interleaved unsigned 8-bit
  * I/Q at 2.4 Msps, nbytes a multiple of 8, decimator state zero at the start.
@@ -179,10 +193,15 @@ int wspr_format_wsprnet_url(const struct decoder_results *r, const struct decode
                             const char *app_version, char *out, size_t cap);
 
 /* ---- kernel-level entry points (parity tests and profiling) --------------- */
-/* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed). */
+/* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed).  symfac is honoured (mode 2,
+ * wsprd.c:250); the decoder itself always passes 50. */
 void sync_and_demodulate(float *id, float *qd, long np, unsigned char *symbols, float *freq,
                          int ifmin, int ifmax, float fstep, int *shift, int lagmin, int lagmax,
                          int lagstep, float *drift, int symfac, float *sync, int mode);
+/* Replaces subtract_signal(), reference wsprd/wsprd.h:83-89 / wsprd.c:263-312 (symbol-by-symbol subtraction;
+ * declared by the reference's header, never called by its decoder; GPU-backed). */
+void subtract_signal(float *id, float *qd, long np, float f0, int shift, float drift,
+                     const unsigned char *channel_symbols);
 /* Replaces subtract_signal2(), reference wsprd/wsprd.h:99-105 (GPU-backed). */
 void subtract_signal2(float *id, float *qd, long np, float f0, int shift, float drift,
                       const unsigned char *channel_symbols);
@@ -306,6 +325,10 @@ int  encode(unsigned char *symbols, unsigned char *data, unsigned int nbytes);
 extern unsigned char Partab[];
 /* reference wsprd/nhash.h:3 */
 uint32_t nhash(const void *key, size_t length, uint32_t initval);
+/* The soft-decision metric tables, reference wsprd/metric_tables.h:8 (a data symbol of the reference's wsprd.o;
+ * rows = Es/No 0, 3, 6, 9 dB and a fifth row whose last eight entries are uninitialised-memory values in the
+ * reference source -- kept as they are).  wspr_decode uses row 2 only (wsprd.c:471-472). */
+extern float metric_tables[5][256];
 /* the integer branch-metric table wspr_decode derives at wsprd/wsprd.c:467-473 */
 void wspr_fano_metric_table(int mettab[2][256]);
 

@@ -385,6 +385,39 @@ void orc_subtract(float *id, float *qd, long np, float f0, int shift, float drif
     free(buf);
 }
 
+/* wsprd.c:263-312: symbol-by-symbol subtraction (exported by wsprd.h:83-89, not called by wspr_decode) */
+void orc_subtract_simple(float *id, float *qd, long np, float f0, int shift, float drift,
+                         const unsigned char *cs) {
+    float c0[ORC_SPS], s0[ORC_SPS];
+    for (int i = 0; i < ORC_NSYM; i++) {
+        float fp = f0 + ((float)drift / 2.0) * ((float)i - (float)ORC_NBITS) / (float)ORC_NBITS;
+        float dphi = kTwoPiDt * (fp + ((float)cs[i] - 1.5) * 375.0 / 256.0);
+        float cdphi = cosf(dphi), sdphi = sinf(dphi);
+        c0[0] = 1; s0[0] = 0;
+        for (int j = 1; j < ORC_SPS; j++) {
+            c0[j] = c0[j - 1] * cdphi - s0[j - 1] * sdphi;
+            s0[j] = c0[j - 1] * sdphi + s0[j - 1] * cdphi;
+        }
+        float i0 = 0.0, q0 = 0.0;
+        for (int j = 0; j < ORC_SPS; j++) {
+            int k = shift + i * ORC_SPS + j;
+            if ((k > 0) && (k < np)) {
+                i0 = i0 + id[k] * c0[j] + qd[k] * s0[j];
+                q0 = q0 - id[k] * s0[j] + qd[k] * c0[j];
+            }
+        }
+        i0 = i0 / (float)ORC_SPS;
+        q0 = q0 / (float)ORC_SPS;
+        for (int j = 0; j < ORC_SPS; j++) {
+            int k = shift + i * ORC_SPS + j;
+            if ((k > 0) && (k < np)) {
+                id[k] = id[k] - (i0 * c0[j] - q0 * s0[j]);
+                qd[k] = qd[k] - (q0 * c0[j] + i0 * s0[j]);
+            }
+        }
+    }
+}
+
 /* ----------------------------------------------------------- orchestration -- */
 /* wsprd.c:416-855, including the hashtable.txt persistence of :481-494 / :842-852 when
  * options.usehashtable is set.  The fftw_wisdom.dat side effect is FFTW-specific and not restated. */

@@ -132,6 +132,8 @@ void orc_sync_demod(const float *id, const float *qd, long np, unsigned char *sy
                     const float *drift, int symfac, float *sync, int mode);
 void orc_subtract(float *id, float *qd, long np, float f0, int shift, float drift,
                   const unsigned char *channel_symbols);
+void orc_subtract_simple(float *id, float *qd, long np, float f0, int shift, float drift,
+                         const unsigned char *channel_symbols);
 int  orc_wspr_decode(float *idat, float *qdat, int samples, orc_options opt,
                      orc_spot *spots, int *n_results, orc_trace *trace);
 

@@ -36,7 +36,7 @@ python3 - "$here/../../include/wspr_mi355x.h" > "$map" <<'PY'
 import re, sys
 src = re.sub(r"/\*.*?\*/", "", open(sys.argv[1]).read(), flags=re.S)
 names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src)) - {"defined"}
-names |= set(re.findall(r"extern\s+[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\]\s*;", src))
+names |= set(re.findall(r"extern\s+[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])+\s*;", src))
 print("{ global: " + " ".join(n + ";" for n in sorted(names)) + " local: *; };")
 PY
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$map" -o "$out" "${objs[@]}" -lpthread

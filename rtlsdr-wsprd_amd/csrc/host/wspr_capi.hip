@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "wspr_message.h"
+#include "wspr_metric_tables.h"
 #include "wspr_pipeline.h"
 
 using wspr::Context;
@@ -62,7 +63,7 @@ namespace {
 template <class Load, class Reload>
 int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
                  int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride) {
-    const int nslots = (nseg >= 128) ? Context::slots() : 1;
+    const int nslots = (nseg >= 128) ? Context::slot_cap() : 1;
     Context& c0 = Context::get();
     if (nslots == 1) {
         load(c0, 0, nseg);
@@ -170,6 +171,63 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
     }
 }
 
+void wspr_shard_range(int nseg, int shard, int nshards, int* lo, int* hi) {
+    if (nshards < 1) nshards = 1;
+    const int base = nseg / nshards, rem = nseg % nshards;
+    const int a = shard * base + (shard < rem ? shard : rem);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (shard < rem ? 1 : 0);
+}
+
+// One host process, every GPU of the node: contiguous blocks of segments, one host thread per device,
+// each block through wspr_decode_batch() on its device (H2D of the block, decode, spots straight into the caller's
+// arrays).  No collective: the segments are independent (wsprd.c:478-479).
+int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
+                           struct decoder_options options, struct decoder_results* decodes, int max_results,
+                           int* n_results, int ndevices) {
+    const int count = wspr_device_count();
+    if (count <= 0) {
+        fprintf(stderr, "libwspr_mi355x: wspr_decode_batch_node: no HIP device visible (there is no CPU fallback)\n");
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return -1;
+    }
+    if (ndevices <= 0) ndevices = count;
+    const char* virt = getenv("WSPR_NODE_VIRTUAL");      // test hook: more shards than devices, folded onto lanes
+    const int per_dev = (ndevices + count - 1) / count;
+    if ((ndevices > count && !(virt && atoi(virt))) || ndevices > Context::kMaxDevices ||
+        Context::lane() + per_dev > Context::kMaxLanes - 1) {
+        fprintf(stderr, "libwspr_mi355x: wspr_decode_batch_node: %d devices asked for, %d visible\n", ndevices, count);
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return -1;
+    }
+    if (options.usehashtable && nseg > 1)                // ordered by definition: nothing to spread
+        return wspr_decode_batch(idat, qdat, nseg, samples, seg_stride, options, decodes, max_results, n_results, 0);
+    int prev = wspr::node_share().load();
+    while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    const int lane0 = Context::lane();
+    int home = 0;
+    (void)hipGetDevice(&home);
+    std::vector<int> rcs(ndevices, 0);
+    std::vector<std::thread> th;
+    for (int k = 0; k < ndevices; ++k) {
+        int lo = 0, hi = 0;
+        wspr_shard_range(nseg, k, ndevices, &lo, &hi);
+        if (hi <= lo) continue;
+        th.emplace_back([=, &rcs] {
+            if (hipSetDevice(k % count) != hipSuccess) { rcs[k] = -1; return; }
+            Context::bind_lane(lane0 + k / count);
+            rcs[k] = wspr_decode_batch(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples,
+                                       seg_stride, options, decodes + (size_t)lo * max_results, max_results,
+                                       n_results + lo, 0);
+        });
+    }
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(home);
+    int rc = 0;
+    for (int k = 0; k < ndevices; ++k) if (rcs[k] < rc) rc = rcs[k];
+    return rc;
+}
+
 int wspr_decode(float* idat, float* qdat, int samples, struct decoder_options options,
                 struct decoder_results* decodes, int* n_results) {
     // the reference caller owns decodes[] with room for its own count (50 in rtlsdr_wsprd.c:117)
@@ -184,10 +242,9 @@ int wspr_decode(float* idat, float* qdat, int samples, struct decoder_options op
 void sync_and_demodulate(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin, int ifmax,
                          float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, int symfac,
                          float* sync, int mode) {
-    (void)symfac;   // the decoder only ever uses 50 (wsprd.c:427); the kernel has it built in
-    try {
+    try {            // symfac scales the soft symbols of mode 2 (wsprd.c:250); the decoder itself always passes 50 (:427)
         Context::get().demod_single(id, qd, np, symbols, freq, ifmin, ifmax, fstep, shift, lagmin, lagmax, lagstep,
-                                    drift, sync, mode);
+                                    drift, sync, mode, symfac);
     } catch (const std::exception& e) { fail("sync_and_demodulate", e); }
 }
 
@@ -195,6 +252,12 @@ void subtract_signal2(float* id, float* qd, long np, float f0, int shift, float 
                       const unsigned char* channel_symbols) {
     try { Context::get().subtract_single(id, qd, np, f0, shift, drift, channel_symbols); }
     catch (const std::exception& e) { fail("subtract_signal2", e); }
+}
+
+void subtract_signal(float* id, float* qd, long np, float f0, int shift, float drift,
+                     const unsigned char* channel_symbols) {
+    try { Context::get().subtract_symbolwise_single(id, qd, np, f0, shift, drift, channel_symbols); }
+    catch (const std::exception& e) { fail("subtract_signal", e); }
 }
 
 int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
@@ -669,6 +732,13 @@ int doublecomp(const void* a, const void* b) {
 int floatcomp(const void* a, const void* b) {
     const float x = *(const float*)a, y = *(const float*)b;
     return x < y ? -1 : (x > y);
+}
+// metric_tables (reference wsprd/metric_tables.h:8): a writable data symbol like the reference's, filled from the
+// bit patterns before anything else runs
+float metric_tables[5][256];
+__attribute__((constructor)) static void metric_tables_init(void) {
+    static_assert(sizeof(metric_tables) == sizeof(kMetricTableBits), "table shape");
+    memcpy(metric_tables, kMetricTableBits, sizeof(metric_tables));
 }
 // 8-bit parity table (reference wsprd/tab.c:7), generated
 unsigned char Partab[256];

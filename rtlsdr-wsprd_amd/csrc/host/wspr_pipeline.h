@@ -19,6 +19,8 @@ namespace wspr {
 std::atomic<unsigned>& fano_fast_budget();
 // -1 automatic, 0 host pool only, 1 device search for every attempt of a batch (see wspr_pipeline.hip)
 std::atomic<int>& fano_device_setting();
+// shards of a node-level call sharing this host's CPUs (see wspr_decode_batch_node)
+std::atomic<int>& node_share();
 
 struct PendingFano {
     std::vector<int> seg;                 // owning segment of each attempt
@@ -52,6 +54,8 @@ public:
     static constexpr int kMaxDevices = 16;
     static int lane();              // lane of the calling thread
     static void bind_lane(int lane);
+    static void cap_slots(int n);   // calling thread: use at most n slots per batch (a shard's share of the host)
+    static int slot_cap();          // min(slots(), the thread's cap, the CPUs of its share)
     int device();
     ~Context();
 
@@ -91,8 +95,10 @@ public:
 
     void demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin, int ifmax,
                       float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, float* sync,
-                      int mode);
+                      int mode, int symfac = 50);
     void subtract_single(float* id, float* qd, long np, float f0, int shift, float drift, const unsigned char* sym);
+    void subtract_symbolwise_single(float* id, float* qd, long np, float f0, int shift, float drift,
+                                    const unsigned char* sym);
     // serial_lanes: the one-lane-per-vector kernel (k6_fano_tail.hip; also fills metric/maxnp of time-outs)
     // instead of the wave-parallel search (k6_fano_wave.hip); steps (may be null): expansion steps per vector
     int fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,

@@ -201,6 +201,13 @@ static int host_cpus() {
     }();
     return n;
 }
+// Shards of one node-level call that share this host's CPUs (wspr_decode_batch_node: one per device): contexts
+// created from then on size their pools for a 1/n share, as a rank of an N-rank job does via WSPR_HOST_THREADS.
+std::atomic<int>& node_share() {
+    static std::atomic<int> v{1};
+    return v;
+}
+static int rank_cpus() { return std::max(1, host_cpus() / std::max(1, node_share().load())); }
 static int usable_cpus() {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
@@ -278,7 +285,7 @@ Context::Context(int nslots) : d(new Impl) {
     d->tab.min_snr = powf(10.0, -8.0 / 10.0);                                        // wsprd.c:590
     d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
 
-    int nthreads = host_cpus();
+    int nthreads = rank_cpus();
     nthreads = std::max(1, std::min(nthreads, 256) / std::max(1, nslots));   // the slots share the host's CPUs
     d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
     d->bigpool.reset(new Pool(nthreads - 1));
@@ -305,7 +312,10 @@ int Context::slots() {
 // made from threads bound to different lanes share nothing but the device and may overlap, which
 // lets a service pipeline batch k+1 under the tail of batch k.
 static thread_local int t_lane = 0;
+static thread_local int t_slot_cap = 8;
 int Context::lane() { return t_lane; }
+void Context::cap_slots(int n) { t_slot_cap = std::max(1, n); }
+int Context::slot_cap() { return std::min(slots(), std::min(t_slot_cap, rank_cpus())); }
 void Context::bind_lane(int lane) { t_lane = std::max(0, std::min(lane, kMaxLanes - 1)); }
 
 // Contexts are kept per (device, lane, slot): a host thread decodes on the HIP device that is current for it
@@ -575,7 +585,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     // small batches gain nothing from the split (their time-outs fit the host pool) and would pay
     // the device kernel's latency
     const bool dev_fano = fano_device_mode() > 0 ||
-                          (fano_device_mode() < 0 && nseg >= 256 && (host_cpus() < 4 || d->crowded));
+                          (fano_device_mode() < 0 && nseg >= 256 && (rank_cpus() < 4 || d->crowded));
     const unsigned fast = (reload && nseg >= 256 && !dev_fano) ? std::min(fast_cfg, 10000u) : 0u;
     d->dev_fano = dev_fano;
     std::vector<int> all(nseg);
@@ -1488,7 +1498,7 @@ void Context::reload_rows(const float* I, const float* Q, bool device, size_t st
 // ------------------------------------------------------- single-call stages --
 void Context::demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin,
                            int ifmax, float fstep, int* shift, int lagmin, int lagmax, int lagstep,
-                           float* drift, float* sync, int mode) {
+                           float* drift, float* sync, int mode, int symfac) {
     Impl& c = *d;
     const int samples = (int)std::min<long>(np, kMaxSamples);
     load_host(id, qd, 1, samples, (size_t)samples);
@@ -1513,7 +1523,7 @@ void Context::demod_single(float* id, float* qd, long np, unsigned char* symbols
         float* d_sync = static_cast<float*>(c.syncbuf.need(4));
         unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need(kNSymD));
         float* d_rms = static_cast<float*>(c.rmsbuf.need(4));
-        launch_demod(wi, wq, (int)np, d_items, 1, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), -INFINITY, d_sync, d_sym, d_rms, c.tab, c.stream);
+        launch_demod(wi, wq, (int)np, d_items, 1, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), -INFINITY, d_sync, d_sym, d_rms, c.tab, c.stream, symfac);
         float s2 = 0;
         HIP_OK(hipMemcpyAsync(&s2, d_sync, 4, hipMemcpyDeviceToHost, c.stream));
         HIP_OK(hipMemcpyAsync(symbols, d_sym, kNSymD, hipMemcpyDeviceToHost, c.stream));
@@ -1538,6 +1548,17 @@ void Context::subtract_single(float* id, float* qd, long np, float f0, int shift
     upload(dj, &jb, sizeof jb, c.stream);
     float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(1) * 4));
     launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), (int)np, dj, 1, scratch, c.tab, c.stream);
+    store_host(id, qd, 1, samples, (size_t)samples);
+}
+
+void Context::subtract_symbolwise_single(float* id, float* qd, long np, float f0, int shift, float drift,
+                                         const unsigned char* sym) {
+    Impl& c = *d;
+    const int samples = (int)std::min<long>(np, kMaxSamples);
+    load_host(id, qd, 1, samples, (size_t)samples);
+    unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need(kNSymD));
+    upload(d_sym, sym, kNSymD, c.stream);
+    launch_subtract_symbolwise(c.iqI.as<float>(), c.iqQ.as<float>(), samples, f0, shift, drift, d_sym, c.stream);
     store_host(id, qd, 1, samples, (size_t)samples);
 }
 

@@ -44,7 +44,7 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
                   const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
                   int nlag, int lagstep, int ifmin, float fstep, const int* __restrict__ jitter,
                   float minsync1, float* __restrict__ sync_out, unsigned char* __restrict__ sym_out,
-                  float* __restrict__ rms_out, const unsigned char* __restrict__ pr3) {
+                  float* __restrict__ rms_out, const unsigned char* __restrict__ pr3, float symfac) {
     __shared__ float pw[kNSymD][4];
     __shared__ float2 tile[kNSymD][kGenChunk + 1];
     const int item = item_list ? item_list[blockIdx.y] : (int)blockIdx.y, hyp = blockIdx.x;
@@ -168,7 +168,7 @@ void demod_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, in
             unsigned char* __restrict__ so = sym_out + o * kNSymD;
             for (int k = 0; k < kNSymD; ++k) {
                 const float f = pr3[k] ? pw[k][3] - pw[k][1] : pw[k][2] - pw[k][0];
-                float v = 50.0f * f / fac;
+                float v = symfac * f / fac;                 // symfac * fsymb[i] / fac, wsprd.c:250 (int -> float)
                 if (v > 127.0f) v = 127.0f;
                 if (v < -128.0f) v = -128.0f;
                 const float w = v + 128.0f;
@@ -1043,11 +1043,11 @@ __global__ void pick_freq_kernel(FineState* __restrict__ items, const int* __res
 void launch_demod(const float* dI, const float* dQ, int samples, const FineState* items, int nitems,
                   int mode, int nlag, int lagstep, int ifmin, float fstep, const int* jitter,
                   float minsync1, float* sync_out, unsigned char* sym_out, float* rms_out,
-                  const DeviceTables& t, hipStream_t st) {
+                  const DeviceTables& t, hipStream_t st, int symfac) {
     if (nitems <= 0 || nlag <= 0) return;
     hipLaunchKernelGGL(demod_kernel, dim3(nlag, nitems), dim3(192), 0, st, dI, dQ, samples, items,
                        (const int*)nullptr, mode, nlag, lagstep, ifmin, fstep, jitter, minsync1, sync_out,
-                       sym_out, rms_out, t.sync);
+                       sym_out, rms_out, t.sync, (float)symfac);
 }
 // Frequency scan (5 hypotheses at +-0.2 Hz, step 0.1) followed by the first ladder rung.
 // Drift-free candidates (list_shared) take the fused tiled path; drifting ones (list_own) the
@@ -1092,11 +1092,11 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
         // scratch_sync is indexed [item][5] by the general kernel
         hipLaunchKernelGGL(demod_kernel, dim3(kNFreq, n_own), dim3(192), 0, st, dI, dQ, samples, items, list_own, 1,
                            kNFreq, lagstep, -2, 0.1f, (const int*)nullptr, 0.0f, scratch_sync, (unsigned char*)nullptr,
-                           (float*)nullptr, t.sync);
+                           (float*)nullptr, t.sync, 50.0f);
         hipLaunchKernelGGL(pick_freq_kernel, dim3((n_own + 63) / 64), dim3(64), 0, st, items, list_own, n_own,
                            scratch_sync, kNFreq, -2, 0.1f);
         hipLaunchKernelGGL(demod_kernel, dim3(1, n_own), dim3(192), 0, st, dI, dQ, samples, items, list_own, 2, 1,
-                           lagstep, 0, 0.0f, jitter0, minsync1, sync_out, sym_out, rms_out, t.sync);
+                           lagstep, 0, 0.0f, jitter0, minsync1, sync_out, sym_out, rms_out, t.sync, 50.0f);
     }
 }
 

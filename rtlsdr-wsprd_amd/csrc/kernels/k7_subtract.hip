@@ -421,7 +421,59 @@ void normalise_kernel(float* __restrict__ dI, float* __restrict__ dQ, const int*
     const float scale = (float)(0.5 / (double)red[0]);
     for (int i = tid; i < n_total; i += 1024) { xi[i] = xi[i] * scale; xq[i] = xq[i] * scale; }
 }
+
+// ---- subtract_signal(), wsprd/wsprd.c:263-312 (symbol-by-symbol subtraction) --------------------------------
+// Exported by the reference's header (wsprd.h:83-89) but never called by its decoder.  The 162 symbols touch
+// disjoint 256-sample spans, so a workgroup owns one symbol: the span is staged, thread 0 walks the reference's
+// two serial loops (phasor recurrence, then the correlation sums in sample order), all threads subtract.
+__global__ __launch_bounds__(256)
+void sub_symbolwise_kernel(float* __restrict__ xi, float* __restrict__ xq, int np, float f0, int shift, float drift,
+                           const unsigned char* __restrict__ sym) {
+    __shared__ float c0[kSps], s0[kSps], si[kSps], sq[kSps], amp[2];
+    const int i = blockIdx.x, j = threadIdx.x;
+    const int k = shift + i * kSps + j;
+    const bool in = (k > 0) && (k < np);
+    si[j] = in ? xi[k] : 0.0f;
+    sq[j] = in ? xq[k] : 0.0f;
+    __syncthreads();
+    if (j == 0) {
+        // float fp = f0 + ((float)drift / 2.0) * ((float)i - (float)NBITS) / (float)NBITS;
+        const float fp = (float)((double)f0 + ((double)drift / 2.0) * (double)((float)i - 81.0f) / (double)81.0f);
+        // float dphi = TWOPIDT * (fp + ((float)cs - 1.5) * DF), the macros expanded in place (all double)
+        const float dphi = (float)(kTwoPiDt * ((double)fp + ((double)(float)sym[i] - 1.5) * 375.0 / 256.0));
+        float sd, cd;
+        glibc_sincosf_pair(dphi, &sd, &cd);
+        float c = 1.0f, s = 0.0f;
+        c0[0] = c; s0[0] = s;
+        for (int t = 1; t < kSps; ++t) {
+            const float cn = c * cd - s * sd, sn = c * sd + s * cd;
+            c = cn; s = sn;
+            c0[t] = c; s0[t] = s;
+        }
+        float a = 0.0f, b = 0.0f;
+        for (int t = 0; t < kSps; ++t) {
+            const int kk = shift + i * kSps + t;
+            if ((kk > 0) && (kk < np)) {
+                a = a + si[t] * c0[t] + sq[t] * s0[t];
+                b = b - si[t] * s0[t] + sq[t] * c0[t];
+            }
+        }
+        amp[0] = a / (float)kSps;
+        amp[1] = b / (float)kSps;
+    }
+    __syncthreads();
+    if (in) {
+        const float a = amp[0], b = amp[1];
+        xi[k] = si[j] - (a * c0[j] - b * s0[j]);
+        xq[k] = sq[j] - (b * c0[j] + a * s0[j]);
+    }
+}
 }  // namespace
+
+void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int shift, float drift,
+                                const unsigned char* d_sym, hipStream_t st) {
+    hipLaunchKernelGGL(sub_symbolwise_kernel, dim3(kNSymD), dim3(kSps), 0, st, dI, dQ, samples, f0, shift, drift, d_sym);
+}
 
 // scratch floats needed for njobs jobs (per job: r and s*conj(r), then the phase-run tables)
 size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kSubPerJob + kTableFloats); }

@@ -116,7 +116,7 @@ void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, i
 void launch_demod(const float* dI, const float* dQ, int samples, const FineState* items, int nitems,
                   int mode, int nhyp, int lagstep, int ifmin, float fstep, const int* jitter,
                   float minsync1, float* sync_out, unsigned char* sym_out, float* rms_out,
-                  const DeviceTables& t, hipStream_t st);
+                  const DeviceTables& t, hipStream_t st, int symfac = 50);
 // Tiled fast path for the wide searches.  FineState.pad must hold the index of the item's
 // first phasor table in `tabs` (1 table if drift == 0, else 162); list_shared/list_own are the
 // item indices without / with drift.  mode 0: nlag lags shift_coarse-128 + lagstep*m;
@@ -141,6 +141,9 @@ void launch_pick_freq(FineState* items, int nitems, const float* sync_in, int nf
 size_t subtract_scratch_floats(int njobs);
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
                      float* scratch /* subtract_scratch_floats(njobs) */, const DeviceTables& t, hipStream_t st);
+// subtract_signal() of the reference (wsprd.c:263-312): one segment row, symbols in device memory
+void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int shift, float drift,
+                                const unsigned char* d_sym, hipStream_t st);
 // Device Fano search (K6) for n soft-symbol vectors symbols[offsets[i]*162 ...] (interleaved order, as
 // the demodulator writes them); metric0 = the 256-entry "sent 0" branch-metric row.
 void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, const short* metric0, int delta,

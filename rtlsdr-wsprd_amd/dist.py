@@ -23,6 +23,74 @@ def shard_range(nseg_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def scatter_segments(I, Q, nseg_total, samples, src=0, device=None):
+    """Fan-out of REAL input (the reference's call sites hold the IQ in one place:
+    rtlsdr_wsprd.c:316 the receiver's buffer, :689 a recorded file).  Rank `src` holds I, Q as
+    [nseg_total, samples] float32 tensors (CPU under gloo, device or CPU under nccl); every rank
+    receives the rows of its shard_range() block -- 2 x samples x 4 bytes (360 000 B for a full
+    2-minute segment) per segment -- as two contiguous tensors [n_r, samples].  One grouped batch of
+    point-to-point sends/receives (ncclSend/ncclRecv inside one group under RCCL, i.e. over the xGMI
+    links out of `src`); no rank sees another's rows.  I, Q are ignored on the other ranks."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else _dev()
+    lo, hi = shard_range(nseg_total, rank, world)
+    if rank == src:
+        assert tuple(I.shape) == (nseg_total, samples) and tuple(Q.shape) == (nseg_total, samples)
+        I = I.to(dev, dtype=torch.float32).contiguous()
+        Q = Q.to(dev, dtype=torch.float32).contiguous()
+        ops = []
+        for r in range(world):
+            if r == src:
+                continue
+            rlo, rhi = shard_range(nseg_total, r, world)
+            if rhi > rlo:
+                ops.append(dist.P2POp(dist.isend, I[rlo:rhi], r))
+                ops.append(dist.P2POp(dist.isend, Q[rlo:rhi], r))
+        mine_i, mine_q = I[lo:hi].clone(), Q[lo:hi].clone()
+    else:
+        mine_i = torch.empty(hi - lo, samples, dtype=torch.float32, device=dev)
+        mine_q = torch.empty(hi - lo, samples, dtype=torch.float32, device=dev)
+        ops = [dist.P2POp(dist.irecv, mine_i, src), dist.P2POp(dist.irecv, mine_q, src)] if hi > lo else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return mine_i, mine_q
+
+
+def gather_spots_sharded(results_array, counts, nseg_total, max_results, record_size, dst=0):
+    """Fan-in for shard_range() blocks of unequal length: every rank pads its records to the longest block, one
+    fixed-size gather, and `dst` puts the rows back into global segment order.
+    Returns on dst (counts int32 [nseg_total], records uint8 [nseg_total, K*record_size]), elsewhere None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(nseg_total, rank, world)
+    longest = max(b - a for a, b in (shard_range(nseg_total, r, world) for r in range(world)))
+    packed = torch.zeros(longest, 4 + max_results * record_size, dtype=torch.uint8)
+    if hi > lo:
+        packed[:hi - lo] = pack_spots(results_array, counts, hi - lo, max_results, record_size)
+    g = gather_spots(packed, dst=dst)
+    if g is None:
+        return None
+    cnt = np.zeros(nseg_total, np.int32)
+    rec = np.zeros((nseg_total, max_results * record_size), np.uint8)
+    allc = unpack_counts(g)
+    for r in range(world):
+        rlo, rhi = shard_range(nseg_total, r, world)
+        cnt[rlo:rhi] = allc[r, :rhi - rlo]
+        rec[rlo:rhi] = g[r, :rhi - rlo, 4:].numpy()
+    return cnt, rec
+
+
+def decode_from_root(I, Q, nseg_total, samples, options, decode_shard, max_results=16, record_size=80, root=0):
+    """The whole fan-out / fan-in around one decode: `root` holds nseg_total segments and the options; the options
+    are broadcast, the IQ rows scattered (scatter_segments), every rank decodes its block with
+    decode_shard(I_rows, Q_rows, options) -> (decoder_results ctypes array [n*max_results], int32 ctypes counts [n]),
+    and the spot records come back to `root` in global segment order (gather_spots_sharded)."""
+    options = broadcast_options(options, src=root)
+    mi, mq = scatter_segments(I, Q, nseg_total, samples, src=root)
+    out, cnt = decode_shard(mi, mq, options)
+    return gather_spots_sharded(out, cnt, nseg_total, max_results, record_size, dst=root)
+
+
 def in_rank_order(fn):
     """Runs fn() on rank 0, then on rank 1, ... with a barrier between the turns, and returns this rank's result.
 
@@ -32,12 +100,27 @@ def in_rank_order(fn):
     turns in rank order over contiguous shards (shard_range) see the segments in global index order -- exactly what
     one reference process walking all of them would produce.  There is nothing to parallelise in that mode; this
     keeps the sharded driver correct for it."""
+    import os
     world, rank = dist.get_world_size(), dist.get_rank()
-    out = None
+    # the turns only mean something if every rank reads and writes the SAME hashtable.txt
+    cwds = [None] * world
+    dist.all_gather_object(cwds, (os.uname().nodename, os.path.realpath(os.getcwd())))
+    if len(set(cwds)) != 1:
+        raise RuntimeError("in_rank_order: the ranks do not share one working directory (hashtable.txt): %r" % (cwds,))
+    out, err = None, None
     for r in range(world):
         if r == rank:
-            out = fn()
+            try:
+                out = fn()
+            except BaseException as e:          # the other ranks wait in the barrier: reach it, then re-raise
+                err = e
         dist.barrier()
+    failed = [None] * world
+    dist.all_gather_object(failed, None if err is None else repr(err))
+    if err is not None:
+        raise err
+    if any(failed):
+        raise RuntimeError("in_rank_order: another rank failed: %r" % ([f for f in failed if f],))
     return out
 
 

@@ -17,7 +17,7 @@ def declared_symbols():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     funcs = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src))
     funcs.discard("defined")
-    data = set(re.findall(r"extern\s+[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\]\s*;", src))
+    data = set(re.findall(r"extern\s+[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])+\s*;", src))
     return funcs, data
 
 
@@ -113,3 +113,38 @@ def test_reference_unit_tests_pass_against_the_product_library():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "18/18 passed, 0 failed" in r.stdout
+
+
+def test_metric_tables_data_symbol():
+    """metric_tables[5][256] (reference wsprd/metric_tables.h:8, a data symbol of the reference's wsprd.o) is exported
+    with the reference's values in all five rows -- the committed fixture, and the mounted header where there is
+    one -- and row 2 yields the integer table wspr_decode derives (wsprd.c:467-473)."""
+    import numpy as np
+    L = w.lib()
+    got = np.ctypeslib.as_array((C.c_float * 1280).in_dll(L, "metric_tables")).reshape(5, 256).copy()
+    want = np.load(os.path.join(ROOT, "tests", "golden", "metric_tables_f32.npy"))
+    assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+    hdr = "/root/reference/wsprd/metric_tables.h"
+    if os.path.exists(hdr):
+        body = open(hdr).read()
+        body = body[body.index("metric_tables[5][256]"):]
+        rows = [[float(x) for x in r.replace("\n", " ").split(",") if x.strip()] for r in re.findall(r"\{([^{}]*)\}", body)[:5]]
+        assert np.array_equal(np.array(rows, np.float64).astype(np.float32).view(np.uint32), got.view(np.uint32))
+    met = ((C.c_int * 256) * 2)()
+    L.wspr_fano_metric_table(met)
+    bias = np.float32(0.45)
+    f = (10.0 * (got[2] - bias).astype(np.float32).astype(np.float64)).astype(np.float32)   # the double product, as a float
+    r2 = (np.sign(f) * np.floor(np.abs(f).astype(np.float64) + 0.5)).astype(int)            # roundf: halves away from zero
+    assert list(met[0]) == r2.tolist() and list(met[1]) == r2[::-1].tolist()
+
+
+def test_shard_range_rule_is_the_drivers():
+    """wspr_shard_range() (the node-level call's split) == rtlsdr-wsprd_amd/dist.py shard_range() (the ranks' split)."""
+    from rtlsdr_wsprd_amd import dist as wd
+    L = w.lib()
+    for nseg in (0, 1, 7, 8, 65536, 1000):
+        for n in (1, 2, 3, 8):
+            for k in range(n):
+                lo, hi = C.c_int(), C.c_int()
+                L.wspr_shard_range(nseg, k, n, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == wd.shard_range(nseg, k, n)

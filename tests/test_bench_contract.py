@@ -27,3 +27,27 @@ def test_command_line_contract():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--inflight"):
         assert flag in out.stdout
+
+
+def _bench(*argv, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                          env=env, timeout=300)
+
+
+def test_gpus_flag_spawns_ranks_or_fails_loudly():
+    """`--gpus N` is honoured by bench.py itself (round-2 verdict: it used to be parsed and ignored).  Without a
+    launcher around it the script re-executes as N ranks; on a node with fewer GPUs it says so and exits non-zero."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this node could really run two ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", env=env)
+    assert r.returncode != 0
+    assert "--gpus 2 but only" in r.stderr and "HIP device(s) visible" in r.stderr
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = _bench("--gpus", "4", env=env)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr

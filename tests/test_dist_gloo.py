@@ -192,3 +192,105 @@ def test_world2_hashtable_segments_in_rank_order(tmp_path):
 @pytest.mark.gpu
 def test_world2_hashtable_segments_in_rank_order_through_the_product(tmp_path):
     _run_hashtable_world2(tmp_path, product=True)
+
+
+# ---- real-input fan-out: rank 0 holds the IQ, the other ranks receive their rows -----------------
+def _root_worker(rank, world, port, q, product, nseg):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rtlsdr_wsprd_amd as w
+    from rtlsdr_wsprd_amd import dist as wd
+    if rank == 0:                                                # ONLY the root has the segments and the options
+        segs = _segments()[:nseg]
+        I = torch.from_numpy(np.stack([s[0] for s in segs])); Q = torch.from_numpy(np.stack([s[1] for s in segs]))
+        opt = w.default_options(npasses=2)
+    else:
+        I = Q = None
+        opt = w.default_options(npasses=1, subtraction=0)
+
+    def decode_shard(mi, mq, o):
+        rows = [(mi[k].numpy(), mq[k].numpy()) for k in range(mi.shape[0])]
+        out, cnt, _ = _decode_shard(0, len(rows), rows, o, product)
+        return out, cnt
+
+    lo, hi = wd.shard_range(nseg, rank, world)
+    res = wd.decode_from_root(I, Q, nseg, 45000, opt, decode_shard, max_results=K, record_size=80, root=0)
+    if rank == 0:
+        cnt, rec = res
+        msgs = [[bytes(rec[s, k * 80 + 28:k * 80 + 51]).split(b"\0")[0].decode() for k in range(cnt[s])] for s in range(nseg)]
+        q.put((cnt.tolist(), msgs))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_root_scatter(product, world=2, nseg=5):
+    sys.path.insert(0, ROOT)
+    import rtlsdr_wsprd_amd as w
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (13 if product else 0) + world
+    procs = [ctx.Process(target=_root_worker, args=(r, world, port, q, product, nseg)) for r in range(world)]
+    for p in procs:
+        p.start()
+    counts, msgs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    segs = _segments()[:nseg]
+    out, cnt, n = _decode_shard(0, nseg, segs, w.default_options())
+    single = [[bytes(out[i * K + k].message).split(b"\0")[0].decode() for k in range(cnt[i])] for i in range(nseg)]
+    assert msgs == single and counts == list(cnt) and sum(counts) >= nseg - 1
+
+
+def test_world2_real_input_scattered_from_root():
+    """Rank 0 alone holds five segments and the options: options broadcast, rows scattered in shard_range() blocks
+    (3 + 2: unequal), every rank decodes what it received, the records come back in global order == one process."""
+    _run_root_scatter(product=False)
+
+
+def test_world3_real_input_scattered_from_root():
+    _run_root_scatter(product=False, world=3, nseg=4)           # blocks of 2, 1, 1
+
+
+@pytest.mark.gpu
+def test_world2_real_input_scattered_from_root_through_the_product():
+    _run_root_scatter(product=True)
+
+
+def _order_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_wsprd_amd import dist as wd
+
+    def turn():
+        if rank == 0:
+            raise ValueError("decoder said no")
+        return rank
+    try:
+        wd.in_rank_order(turn)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, "own: %s" % e))
+    except RuntimeError as e:
+        q.put((rank, "other: %s" % e))
+    dist.destroy_process_group()
+
+
+def test_in_rank_order_does_not_hang_when_a_rank_fails():
+    """A rank whose turn raises still reaches every barrier; it re-raises its own error afterwards and the other
+    ranks learn that a turn failed (round-2 advisor finding: they used to block forever)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0].startswith("own: decoder said no") and got[1].startswith("other:")

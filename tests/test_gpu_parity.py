@@ -107,6 +107,38 @@ def test_candidates_match_oracle(w, synth_batch, ref_iq, coarse):
             assert g.snr == o.snr                                   # ranked and reported with the host libm
 
 
+def test_equal_snr_ties_keep_the_reference_order(w):
+    """Candidates with EXACTLY equal snr (wsprd.c:616, 631: qsort of a list built in ascending bin order; glibc's
+    qsort is a stable merge sort at this size, so ties stay in bin order).  A real-valued record (Q = 0) has a
+    mirror-symmetric spectrum, bit for bit, so every peak comes with a twin of identical snr at the mirrored
+    frequency: the product's host re-rank must put the twins in the oracle's order -- they are then refined,
+    decoded and subtracted in that order."""
+    rng = np.random.default_rng(5)
+    t = np.arange(NS) / 375.0
+    recs = []
+    for f1, f2, f3 in ((40.3, 77.7, 12.1), (5.5, 93.0, 61.2)):
+        recs.append((0.02 * rng.normal(size=NS) + 0.3 * np.cos(2 * np.pi * f1 * t) + 0.2 * np.cos(2 * np.pi * f2 * t)
+                     + 0.1 * np.cos(2 * np.pi * f3 * t)).astype(np.float32))
+    I = np.stack(recs)
+    Q = np.zeros_like(I)
+    for coarse in (0, 1):
+        cands = (w.cand * (200 * 2))()
+        npk = (C.c_int * 2)()
+        assert w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), 2, NS, NS, coarse, 4, C.addressof(cands),
+                                             C.addressof(npk), None, None) == 0
+        for s in range(2):
+            onpk, oc, _, _ = _oracle_cands(I[s], Q[s], coarse)
+            assert npk[s] == onpk and onpk >= 6
+            snrs = [oc[j].snr for j in range(onpk)]
+            assert len(snrs) - len(set(snrs)) >= 3                   # the twins really tie
+            for j in range(onpk):
+                g, o = cands[200 * s + j], oc[j]
+                assert (g.freq, g.snr, g.shift, g.drift, g.sync) == (o.freq, o.snr, o.shift, o.drift, o.sync), (s, j)
+    # and through the whole decoder (nothing decodes; the residuals and the empty spot lists agree)
+    got = w.wspr_decode_batch(I, Q, w.default_options(), max_results=8)
+    assert [len(g) for g in got] == [len(ol.decode(I[s], Q[s], NS)[0]) for s in range(2)]
+
+
 @pytest.mark.parametrize("maxdrift", [4, 0])
 def test_coarse_sync_of_a_large_batch_matches_oracle(w, synth_batch, ref_iq, maxdrift):
     """Batches of 1 536 segments and more take the lane-per-(candidate, lag) coarse-sync kernel (one lane holds the
@@ -140,14 +172,15 @@ def test_coarse_sync_of_a_large_batch_matches_oracle(w, synth_batch, ref_iq, max
 
 
 # ------------------------------------------------------------------ K4 / K5
-def _both_demod(w, I, Q, freq, shift, drift, mode, lagmin=0, lagmax=0, lagstep=8, ifmin=0, ifmax=0, fstep=0.0, np_=NS):
+def _both_demod(w, I, Q, freq, shift, drift, mode, lagmin=0, lagmax=0, lagstep=8, ifmin=0, ifmax=0, fstep=0.0, np_=NS,
+                symfac=50):
     res = []
     for which in ("gpu", "cpu"):
         Ic, Qc = I.copy(), Q.copy()
         f = C.c_float(freq); sh = C.c_int(shift); dr = C.c_float(drift); sy = C.c_float(0)
         sym = (C.c_ubyte * 162)()
         args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(np_), sym, C.addressof(f), ifmin, ifmax, C.c_float(fstep),
-                C.addressof(sh), lagmin, lagmax, lagstep, C.addressof(dr), 50, C.addressof(sy), mode]
+                C.addressof(sh), lagmin, lagmax, lagstep, C.addressof(dr), symfac, C.addressof(sy), mode]
         if which == "gpu":
             w.lib().sync_and_demodulate(*args)
         else:
@@ -185,7 +218,39 @@ def test_sync_and_demodulate_edges(w, synth_batch):
     assert g[2:] == o[2:]
 
 
+@pytest.mark.parametrize("symfac", [50, 64, 20, 127, 1])
+def test_sync_and_demodulate_honours_symfac(w, synth_batch, symfac):
+    """wsprd.c:250: the soft symbols of mode 2 are scaled by the caller's symfac (the decoder passes 50; round 2
+    ignored every other value)."""
+    I, Q, truth = synth_batch
+    msg, f0, t0, snr = truth[1][0]
+    g, o = _both_demod(w, I[1], Q[1], float(np.float32(f0)), int(round(t0 * 375)), 0.0, 2, symfac=symfac)
+    assert g[2] == o[2] and g[3] == o[3]
+    if symfac != 50:
+        base = _both_demod(w, I[1], Q[1], float(np.float32(f0)), int(round(t0 * 375)), 0.0, 2)[0]
+        assert base[3] != g[3]
+
+
 # ------------------------------------------------------------------ K7
+@pytest.mark.parametrize("seg,drift,shift_off,np_", [(0, 0.0, 0, NS), (6, 0.0, 0, NS), (7, 2.0, 0, NS), (1, 0.0, -2500, NS),
+                                                     (2, -1.0, 3900, NS), (3, 0.5, 0, 30000)])
+def test_subtract_signal_symbolwise_bit_exact(w, synth_batch, seg, drift, shift_off, np_):
+    """subtract_signal() (wsprd.h:83-89, wsprd.c:263-312): exported by the reference, not called by its decoder."""
+    I, Q, truth = synth_batch
+    msg, f0, t0, snr = truth[seg][0]
+    sym = symf(msg)
+    shift = int(round(t0 * 375)) + shift_off
+    outs = []
+    for which in ("gpu", "cpu"):
+        Ic, Qc = I[seg].copy(), Q[seg].copy()
+        args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(np_), C.c_float(f0), C.c_int(shift), C.c_float(drift), ol.ptr(sym)]
+        (w.lib().subtract_signal if which == "gpu" else ol.lib().orc_subtract_simple)(*args)
+        outs.append((Ic, Qc))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert not np.array_equal(outs[0][0], I[seg])
+    assert np.array_equal(outs[0][0][np_:], I[seg][np_:])          # nothing beyond np is touched
+
+
 @pytest.mark.parametrize("seg,drift,shift_off", [(0, 0.0, 0), (6, 0.0, 0), (7, 2.0, 0), (1, 0.0, -2500), (2, -1.0, 3900)])
 def test_subtract_signal2_bit_exact(w, synth_batch, seg, drift, shift_off):
     I, Q, truth = synth_batch
@@ -681,3 +746,36 @@ def test_hashtable_option_on_a_batch_decodes_in_order(w, tmp_path):
     # without the option the hashed call cannot be resolved in a fresh batch
     plain = w.wspr_decode_batch(I, Q, _opt(w, 0))
     assert [x.message for x in plain[2]] != [b"<PJ4/K1ABC> FK52UD 37"]
+
+
+# ------------------------------------------------------------------ node-level call
+def _node(w, I, Q, ndev, max_results=16):
+    nseg = I.shape[0]
+    out = (w.decoder_results * (nseg * max_results))()
+    nres = (C.c_int * nseg)()
+    rc = w.lib().wspr_decode_batch_node(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, w.default_options(), C.addressof(out),
+                                        max_results, C.addressof(nres), ndev)
+    return rc, [[_spot_tuple(out[s * max_results + i]) for i in range(nres[s])] for s in range(nseg)]
+
+
+def test_node_level_call_equals_one_device_batch(w, synth_batch, monkeypatch):
+    """wspr_decode_batch_node(): contiguous blocks over the node's devices, one host thread each.  On this 1-GPU box:
+    all devices (= 1), and -- with the test hook WSPR_NODE_VIRTUAL -- three blocks of 3/3/2 segments decoded
+    concurrently on three lanes of the one device.  Same spots as one wspr_decode_batch(); asking for devices that
+    do not exist is an error."""
+    I, Q, _ = synth_batch
+    L = w.lib()
+    L.wspr_decode_batch_node.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    want = [[_spot_tuple(x) for x in seg] for seg in w.wspr_decode_batch(I, Q, w.default_options(), max_results=16)]
+    rc, got = _node(w, I, Q, 0)
+    assert rc == 0 and got == want
+    ndev = L.wspr_device_count()
+    rc, got = _node(w, I, Q, ndev + 2)
+    assert rc == -1 and all(len(g) == 0 for g in got)
+    monkeypatch.setenv("WSPR_NODE_VIRTUAL", "1")
+    rc, got = _node(w, I, Q, 3 * ndev)
+    assert rc == 0 and got == want
+    lo, hi = C.c_int(), C.c_int()
+    L.wspr_shard_range(8, 1, 3, C.byref(lo), C.byref(hi))
+    assert (lo.value, hi.value) == (3, 6)
