@@ -92,6 +92,43 @@ int wspr_decode_batch_device(const void *d_idat, const void *d_qdat, int nseg, i
                              size_t seg_stride, struct decoder_options options,
                              struct decoder_results *decodes, int max_results, int *n_results);
 
+/* Per-candidate trace of the fine search (the reference's candidate loop, wsprd.c:697-822): what the production
+ * kernels -- lag scan, frequency scan fused with rung 0, the 43-lag ladder block, the Fano search -- produced for
+ * EVERY candidate the loop entered, whether it decoded or not.  Same launches as wspr_decode_batch(); the only
+ * differences are extra device-to-host copies and that the Fano budget split is off (every attempt runs the
+ * reference's full budget where it is first met).  For parity tests against the oracle's trace. */
+#define WSPR_TRACE_PASSES 3
+typedef struct wspr_cand_trace {
+    int   visited;              /* the loop entered this candidate (it may have left the segment early, :786-793) */
+    int   mode0_shift;          /* after sync_and_demodulate(mode 0), wsprd.c:709-719 */
+    float mode0_sync;
+    float freq;                 /* after mode 1, :721-726: what the reference writes back to candidates[j] */
+    int   shift;
+    float drift;
+    float sync;
+    int   attempts;             /* mode-2 calls of the jitter ladder, :739-766 (0: sync <= minsync1) */
+    int   fano_calls;           /* of which passed the sync/rms gates (:759) and reached fano() */
+    float first_sync;           /* rung 0 of the ladder: sync, rms and the 162 soft symbols (transmission order) */
+    float first_rms;
+    int   decoded;
+    int   subtracted;
+    int   jitter;
+    unsigned cycles;
+    unsigned char first_symbols[162];
+    unsigned char decdata[11];
+    unsigned char pad[3];
+} wspr_cand_trace;
+typedef struct wspr_trace {
+    int passes_run;
+    int npk[WSPR_TRACE_PASSES];
+    int n_visited[WSPR_TRACE_PASSES];
+    wspr_cand_trace cand[WSPR_TRACE_PASSES][MAX_CANDIDATES];
+} wspr_trace;
+/* wspr_decode_batch() (host buffers, inputs untouched) that also fills trace[0..nseg). */
+int wspr_decode_batch_trace(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
+                            struct decoder_options options, struct decoder_results *decodes,
+                            int max_results, int *n_results, wspr_trace *trace);
+
 /* Node-level form (SURVEY §8e "one host process, 8 devices"): the nseg host segments are split into contiguous
  * blocks by wspr_shard_range() over `ndevices` HIP devices (0 = every visible device; more than are visible is an
  * error), one host thread per device, each block decoded by wspr_decode_batch() on its device straight into the

@@ -45,6 +45,22 @@ class cand(C.Structure):                     # wsprd/wsprd.h:54-60
                 ("drift", C.c_float), ("sync", C.c_float)]
 
 
+TRACE_PASSES = 3
+
+
+class cand_trace(C.Structure):               # include/wspr_mi355x.h: wspr_cand_trace
+    _fields_ = [("visited", C.c_int), ("mode0_shift", C.c_int), ("mode0_sync", C.c_float),
+                ("freq", C.c_float), ("shift", C.c_int), ("drift", C.c_float), ("sync", C.c_float),
+                ("attempts", C.c_int), ("fano_calls", C.c_int), ("first_sync", C.c_float), ("first_rms", C.c_float),
+                ("decoded", C.c_int), ("subtracted", C.c_int), ("jitter", C.c_int), ("cycles", C.c_uint),
+                ("first_symbols", C.c_ubyte * NSYM), ("decdata", C.c_ubyte * 11), ("pad", C.c_ubyte * 3)]
+
+
+class trace(C.Structure):                    # include/wspr_mi355x.h: wspr_trace
+    _fields_ = [("passes_run", C.c_int), ("npk", C.c_int * TRACE_PASSES), ("n_visited", C.c_int * TRACE_PASSES),
+                ("cand", (cand_trace * MAX_CANDIDATES) * TRACE_PASSES)]
+
+
 def default_options(freq=144489000, npasses=2, subtraction=1, quickmode=0):
     """initDecoder_options(), rtlsdr_wsprd.c:357-362."""
     return decoder_options(freq=freq, quickmode=quickmode, usehashtable=0,
@@ -150,6 +166,25 @@ def wspr_decode_batch(I, Q, options=None, max_results=50):
     if rc < 0:
         raise RuntimeError("wspr_decode_batch failed (rc %d: no usable HIP device, or usehashtable on a batch)" % rc)
     return [[out[s * max_results + i] for i in range(nres[s])] for s in range(nseg)]
+
+
+def wspr_decode_batch_trace(I, Q, options=None, max_results=50):
+    """wspr_decode_batch() + the per-candidate trace of the fine search (what the production kernels produced for
+    every candidate the reference's loop enters).  Returns (spot lists, trace array [nseg])."""
+    I = np.ascontiguousarray(I, dtype=np.float32)
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    nseg, samples = I.shape
+    out = (decoder_results * (nseg * max_results))()
+    nres = (C.c_int * nseg)()
+    tr = (trace * nseg)()
+    L = lib()
+    L.wspr_decode_batch_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, decoder_options,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.wspr_decode_batch_trace(_ptr(I), _ptr(Q), nseg, samples, samples, options or default_options(),
+                                   C.addressof(out), max_results, C.addressof(nres), C.addressof(tr))
+    if rc < 0:
+        raise RuntimeError("wspr_decode_batch_trace failed (rc %d)" % rc)
+    return [[out[s * max_results + i] for i in range(nres[s])] for s in range(nseg)], tr
 
 
 def sync_torch():

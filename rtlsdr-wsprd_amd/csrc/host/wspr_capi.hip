@@ -62,13 +62,14 @@ namespace {
 // contiguous share on its own stream while the others are in their host phases.
 template <class Load, class Reload>
 int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
-                 int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride) {
+                 int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
+                 wspr_trace* trace = nullptr) {
     const int nslots = (nseg >= 128) ? Context::slot_cap() : 1;
     Context& c0 = Context::get();
     if (nslots == 1) {
         load(c0, 0, nseg);
         const int rc = c0.decode_resident(nseg, samples, options, decodes, max_results, n_results,
-                                          [&](const std::vector<int>& segs) { reload(c0, 0, segs); });
+                                          [&](const std::vector<int>& segs) { reload(c0, 0, segs); }, trace);
         if (writeback) c0.store_host(idat, qdat, nseg, samples, seg_stride);
         return rc;
     }
@@ -85,7 +86,8 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
                 Context& c = Context::slot(g);
                 load(c, lo, hi - lo);
                 rcs[g] = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results,
-                                           n_results + lo, [&c, &reload, lo](const std::vector<int>& segs) { reload(c, lo, segs); });
+                                           n_results + lo, [&c, &reload, lo](const std::vector<int>& segs) { reload(c, lo, segs); },
+                                           trace ? trace + lo : nullptr);
                 if (writeback) c.store_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples, seg_stride);
             } catch (const std::exception& e) { rcs[g] = -1; errs[g] = e.what(); }
         });
@@ -141,6 +143,31 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return fail("wspr_decode_batch", e);
+    }
+}
+
+int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
+                            struct decoder_options options, struct decoder_results* decodes, int max_results,
+                            int* n_results, wspr_trace* trace) {
+    if (!trace) return -1;
+    if (options.usehashtable && nseg > 1)
+        return decode_in_order(nseg, n_results, [&](int s) {
+            return wspr_decode_batch_trace(idat + (size_t)s * seg_stride, qdat + (size_t)s * seg_stride, 1, samples, seg_stride,
+                                           options, decodes + (size_t)s * max_results, max_results, n_results + s, trace + s);
+        });
+    try {
+        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        return decode_split(nseg, samples, options, decodes, max_results, n_results,
+                            [&](Context& c, int lo, int n) {
+                                c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
+                            },
+                            [&](Context& c, int lo, const std::vector<int>& segs) {
+                                c.reload_rows(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, false, seg_stride, samples, segs);
+                            },
+                            false, idat, qdat, seg_stride, trace);
+    } catch (const std::exception& e) {
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return fail("wspr_decode_batch_trace", e);
     }
 }
 

@@ -85,10 +85,11 @@ public:
     // for the exact re-decode after a late Fano success); empty function = no fast/tail split
     int decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
                         int max_results, int* n_results,
-                        const std::function<void(const std::vector<int>&)>& reload = nullptr);
+                        const std::function<void(const std::vector<int>&)>& reload = nullptr,
+                        wspr_trace* trace = nullptr);
     int decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
                     int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend,
-                    const FanoMemo* memo = nullptr);
+                    const FanoMemo* memo = nullptr, wspr_trace* trace = nullptr);
     int last_timings(double* ms, int cap);
     int bench_fft_sync(int nseg, int samples, int iters, double* ms);
     int bench_valu(int nseg, int samples, int iters, double* ms);

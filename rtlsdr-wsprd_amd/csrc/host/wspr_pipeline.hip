@@ -571,7 +571,8 @@ std::atomic<unsigned>& fano_fast_budget() {
 }
 
 int Context::decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
-                             int max_results, int* n_results, const std::function<void(const std::vector<int>&)>& reload) {
+                             int max_results, int* n_results, const std::function<void(const std::vector<int>&)>& reload,
+                             wspr_trace* trace) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
     c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0;
@@ -586,12 +587,14 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     // the device kernel's latency
     const bool dev_fano = fano_device_mode() > 0 ||
                           (fano_device_mode() < 0 && nseg >= 256 && (rank_cpus() < 4 || d->crowded));
-    const unsigned fast = (reload && nseg >= 256 && !dev_fano) ? std::min(fast_cfg, 10000u) : 0u;
+    // a traced decode runs every attempt with the full budget where it is first met (nothing provisional)
+    const unsigned fast = (reload && nseg >= 256 && !dev_fano && !trace) ? std::min(fast_cfg, 10000u) : 0u;
+    if (trace) memset(trace, 0, (size_t)nseg * sizeof(wspr_trace));
     d->dev_fano = dev_fano;
     std::vector<int> all(nseg);
     for (int s = 0; s < nseg; ++s) all[s] = s;
     PendingFano pend;
-    decode_core(nseg, samples, opt, out, max_results, n_results, all, fast >= 10000u ? 0u : fast, pend);
+    decode_core(nseg, samples, opt, out, max_results, n_results, all, fast >= 10000u ? 0u : fast, pend, nullptr, trace);
     if (!pend.seg.empty()) {
         // ---- finish the provisional failures on the device, full budget ----------------------
         const auto t_t0 = std::chrono::steady_clock::now();
@@ -638,6 +641,12 @@ struct Context::DecodeRun {
     const unsigned fast;                      // host Fano budget (cycles per bit) or 0 = the reference's
     PendingFano& pend;
     const FanoMemo* memo = nullptr;           // results already known (re-decode after a late success)
+    wspr_trace* trace = nullptr;              // per-candidate record of the fine search (wspr_decode_batch_trace)
+    struct ItemTrace {                        // one wave item's share of it, filled as the wave proceeds
+        int m0_shift = 0; float m0_sync = 0; float sync0 = 0, rms0 = 0; int attempts = 0, fano_calls = 0;
+        unsigned char sym0[kNSymD];
+    };
+    std::vector<ItemTrace> wtrace;
 
     // one Fano attempt on a soft-symbol vector in transmission order (wsprd.c:759-761)
     // ladder = an attempt on rungs 1..42 (those rarely decode: with the budget split on they get the shorter
@@ -768,6 +777,8 @@ void Context::DecodeRun::start_pass(int pass, const std::vector<int>& active) {
         c.resolve_deferred();
     }
     ctx.finish_fetch_candidates(nseg, npk, cand);
+    if (trace && ipass < WSPR_TRACE_PASSES)
+        for (int s : active) { trace[s].passes_run = ipass + 1; trace[s].npk[ipass] = npk[s]; }
     lockstep = opt.subtraction && ipass == 0;
     stopped.assign(nseg, 0);
     next_cand.assign(nseg, 0);
@@ -872,6 +883,14 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
         launch_demod_tiled(wi, wq, samples, d_items, nw, d_lists, n_shared, d_lists + nw, n_own, 0, nlag0, lagstep,
                            0.0f, d_tabs, d_pw, d_sync, nullptr, nullptr, c.tab, c.stream);
         launch_pick_lag(d_items, nw, d_sync, nlag0, lagstep, c.stream);
+        std::vector<FineState> tr_items0;
+        if (trace) {                                           // mode-0 result, before the frequency scan refines it
+            tr_items0.resize(nw);
+            HIP_OK(hipMemcpyAsync(tr_items0.data(), d_items, (size_t)nw * sizeof(FineState), hipMemcpyDeviceToHost, c.stream));
+            HIP_OK(hipStreamSynchronize(c.stream));
+            wtrace.assign(nw, ItemTrace{});
+            for (int i = 0; i < nw; ++i) { wtrace[i].m0_shift = tr_items0[i].shift; wtrace[i].m0_sync = tr_items0[i].sync; }
+        }
         {
             float* d_tabs1 = static_cast<float*>(c.tabs.need(std::max(ntabs, (size_t)n_shared * 5) * 2048 * 4));
             float* d_scr = static_cast<float*>(c.scrsync.need((size_t)nw * 5 * 4));
@@ -882,7 +901,7 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
                                             d_rms0, c.tab, c.stream, d_pw, nlag0);
         }
         // device-Fano mode: the soft symbols stay in HBM, only items / sync / rms come down
-        HIP_OK(hipMemcpyAsync(h_down, d_blk, c.dev_fano ? o_sym : down_bytes, hipMemcpyDeviceToHost, c.stream));
+        HIP_OK(hipMemcpyAsync(h_down, d_blk, (c.dev_fano && !trace) ? o_sym : down_bytes, hipMemcpyDeviceToHost, c.stream));
         t.stop();
         c.resolve_deferred();
     }
@@ -892,6 +911,16 @@ void Context::DecodeRun::refine_and_first_rung(std::vector<WaveItem>& wave) {
     h_rms = reinterpret_cast<float*>(h_down + o_rms);
     h_sym = reinterpret_cast<unsigned char*>(h_down + o_sym);
 
+    if (trace)
+        for (int i = 0; i < nw; ++i) {
+            ItemTrace& t = wtrace[i];
+            const bool worth = h_items[i].sync > minsync1;   // rung 0 is only computed for these (wsprd.c:733-737)
+            t.attempts = worth ? 1 : 0;
+            if (!worth) continue;
+            t.sync0 = h_sync[i]; t.rms0 = h_rms[i];
+            memcpy(t.sym0, h_sym + (size_t)i * kNSymD, kNSymD);
+            t.fano_calls = (h_sync[i] > minsync2 && h_rms[i] > minrms) ? 1 : 0;
+        }
     // ---- first rung of the jitter ladder -----------------------------------
     const auto t_f0 = std::chrono::steady_clock::now();
     if (c.dev_fano) {
@@ -984,6 +1013,16 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             h_rms = reinterpret_cast<float*>(h_blk + o_rms);
             h_sym = reinterpret_cast<unsigned char*>(h_blk + o_sym);
         }
+        // trace: the serial walk stops at the first success, rung `lastr` of the rest (or walks all of them)
+        auto trace_ladder = [&](int a, int lastr) {
+            if (!trace) return;
+            ItemTrace& t = wtrace[again[a]];
+            t.attempts = 1 + (lastr + 1);
+            for (int r = 0; r <= lastr; ++r) {
+                const int g = a * kMaxLags + (c.jitter_ladder[r + 1] + 63) / 3;
+                if (h_sync[g] > minsync2 && h_rms[g] > minrms) t.fano_calls++;
+            }
+        };
         if (c.dev_fano) {
             // every gated (candidate, rung) vector to the device search; the ladder keeps the first success in
             // rung order, so all are run and the pick is made afterwards (a candidate that decodes on an early
@@ -1007,6 +1046,7 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
                 if (ret[k] == 0 && r < first[a]) { first[a] = r; at[a] = k; }
             }
             for (int a = 0; a < na; ++a) {
+                trace_ladder(a, at[a] >= 0 ? first[a] : njit_rest - 1);
                 if (at[a] < 0) continue;
                 WaveItem& w = wave[again[a]];
                 w.decoded = true;
@@ -1058,6 +1098,7 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             }
         for (int a = 0; a < na; ++a) {
             const int r = first[a].load();
+            trace_ladder(a, (r < njit_rest && att[(size_t)a * njit_rest + r].ok) ? r : njit_rest - 1);
             if (r < njit_rest && att[(size_t)a * njit_rest + r].ok) {
                 WaveItem& w = wave[again[a]];
                 w.decoded = true;
@@ -1093,6 +1134,22 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         if (lockstep) next_cand[s] = w.cand + 1;
         DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
         cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
+        wspr_cand_trace* tc = nullptr;
+        if (trace && ipass < WSPR_TRACE_PASSES) {            // this visit is the one that counts (not a dropped speculation)
+            const ItemTrace& t = wtrace[i];
+            tc = &trace[s].cand[ipass][w.cand];
+            memset(tc, 0, sizeof *tc);
+            trace[s].n_visited[ipass] = w.cand + 1;
+            tc->visited = 1;
+            tc->mode0_shift = t.m0_shift; tc->mode0_sync = t.m0_sync;
+            tc->freq = w.fine.freq; tc->shift = w.fine.shift; tc->drift = w.fine.drift; tc->sync = w.fine.sync;
+            tc->attempts = t.attempts; tc->fano_calls = t.fano_calls;
+            if (t.attempts > 0) { tc->first_sync = t.sync0; tc->first_rms = t.rms0; memcpy(tc->first_symbols, t.sym0, kNSymD); }
+            if (w.worth && w.decoded) {
+                tc->decoded = 1; tc->jitter = w.jitter; tc->cycles = w.cycles;
+                memcpy(tc->decdata, w.decdata, 11);
+            }
+        }
         if (!(w.worth && w.decoded)) continue;
 
         signed char message[12] = {0};
@@ -1107,6 +1164,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
                 jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
                 job_of[i] = jb;
                 has_job[i] = 1;
+                if (tc) tc->subtracted = 1;
                 cut = true;            // the IQ changes: later candidates of this window are redone
             } else {
                 stopped[s] = 1;                      // wsprd.c:786-788: leaves the candidate loop
@@ -1207,10 +1265,11 @@ void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results)
 // records every attempt it could not finish in `pend` (see decode_resident).
 int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
                          int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend,
-                         const FanoMemo* memo) {
+                         const FanoMemo* memo, wspr_trace* trace) {
     for (int s : active0) n_results[s] = 0;
     DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
     run.memo = memo;
+    run.trace = trace;
     // whatever happens below (a HIP error surfaces as an exception), the call signs this run wrote into the
     // context's hash memory must not survive into the next batch on this lane/slot
     struct HashGuard {

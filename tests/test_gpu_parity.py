@@ -296,16 +296,14 @@ def test_batch_decode_equals_oracle(w, synth_batch, opts):
             assert [x.message.decode() for x in got[s]] == [synth.expected_text(truth[s][0][0])]
 
 
-def test_randomised_scenes_equal_oracle(w):
-    """Forty random scenes the fixed fixtures do not cover: 0-6 signals of type 1/2/3, SNR -31..+6 dB,
-    drifts -3..+3 Hz, starts 0.2..3.8 s (part of the frame may fall off either end), carriers out to
-    +-125 Hz (beyond the +-110 Hz candidate window), two signals a few Hz apart, a strong CW carrier, and
-    a segment of plain noise.  Every spot field must equal the oracle's (SNR within the stated 0.1 dB)."""
-    rng = np.random.default_rng(int(os.environ.get("WSPR_SCENE_SEED", "20260928")))
+def random_scenes(count=None, seed=None):
+    """The randomised scenes of test_randomised_scenes_equal_oracle (also traced per candidate in test_gpu_trace.py)."""
+
+    rng = np.random.default_rng(int(os.environ.get("WSPR_SCENE_SEED", "20260928")) if seed is None else seed)
     sigma = np.sqrt((375.0 / 2500.0) / 2.0)
     t23 = ["PJ4/K1ABC 37", "K1ABC/7 33", "<PJ4/K1ABC> FK52UD 37"]
     Is, Qs = [], []
-    for scene in range(int(os.environ.get("WSPR_SCENES", "40"))):      # (a longer soak: WSPR_SCENES=400)
+    for scene in range(int(os.environ.get("WSPR_SCENES", "40")) if count is None else count):      # (a longer soak: WSPR_SCENES=400)
         I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
         nsig = 0 if scene == 0 else int(rng.integers(1, 7))
         base = rng.uniform(-125, 125, nsig)
@@ -322,6 +320,15 @@ def test_randomised_scenes_equal_oracle(w):
         a, b = synth.normalise(I.astype(np.float32), Q.astype(np.float32))
         Is.append(a); Qs.append(b)
     I = np.stack(Is); Q = np.stack(Qs)
+    return I, Q
+
+
+def test_randomised_scenes_equal_oracle(w):
+    """Forty random scenes the fixed fixtures do not cover: 0-6 signals of type 1/2/3, SNR -31..+6 dB,
+    drifts -3..+3 Hz, starts 0.2..3.8 s (part of the frame may fall off either end), carriers out to
+    +-125 Hz (beyond the +-110 Hz candidate window), two signals a few Hz apart, a strong CW carrier, and
+    a segment of plain noise.  Every spot field must equal the oracle's (SNR within the stated 0.1 dB)."""
+    I, Q = random_scenes()
     got = w.wspr_decode_batch(I, Q, w.default_options())
     total = 0
     for s in range(I.shape[0]):
