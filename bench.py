@@ -185,6 +185,68 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
                       "segments/s" % (n, cores, os.cpu_count() or 0, 1.0 / one)}, res
 
 
+def k0_report(L, m, with_cpu=True):
+    """Roofline of the front end (K0, the HBM-bound kernel of configs[4]) on the resident raw segments of measurement
+    `m`, HIP events on the launch stream, and the decimator's CPU baseline (the oracle's restatement of
+    rtlsdr_callback(), rtlsdr_wsprd.c:126-244, over one whole 576 MB segment per host thread)."""
+    raw, nraw = m["raw"], m["raw"].shape[0]
+    I, Q = m["I"], m["Q"]
+    kms = (C.c_double * 1)()
+    # 5 launches to settle, then three sets of 10 (all reported, the best one is the figure)
+    L.wspr_bench_decimate(raw.data_ptr(), RAW_BYTES, nraw, I.data_ptr(), Q.data_ptr(), 5, C.addressof(kms))
+    k0_sets = []
+    for _ in range(3):
+        L.wspr_bench_decimate(raw.data_ptr(), RAW_BYTES, nraw, I.data_ptr(), Q.data_ptr(), 10, C.addressof(kms))
+        k0_sets.append(kms[0])
+    best = min(k0_sets)
+    k0_bytes = (RAW_BYTES + 360000) * nraw
+    rms = (C.c_double * 1)()
+    L.wspr_calib_read(raw.data_ptr(), RAW_BYTES, nraw, 10, C.addressof(rms))
+    out = {"bound": "hbm", "kernel": "cic_block_sums_fast_kernel + cic_comb_fir_kernel + normalise_kernel",
+           "segments_per_launch": nraw, "avg_launch_ms": best, "bytes_per_launch": k0_bytes,
+           "achieved_GBs": k0_bytes / (best * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+           "frac": k0_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "segments_per_second_bound_at_this_rate": nraw / (best * 1e-3),
+           "avg_launch_ms_of_each_set_of_10": k0_sets,
+           # the same rows read by a kernel with K0's access pattern and no arithmetic
+           "measured_read_GBs": RAW_BYTES * nraw / (rms[0] * 1e-3) / 1e9}
+    if with_cpu:
+        import oracle_lib as ol
+        from concurrent.futures import ThreadPoolExecutor
+        O = ol.lib()
+        cores = usable_cpus()
+        host = raw[0].cpu().numpy()                              # one raw segment; every thread decimates it (read-only)
+
+        def one(full):
+            st = O.orc_decim_new()
+            oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+            n = O.orc_decim_feed(C.c_void_p(st), ol.ptr(host), host.size, ol.ptr(oi), ol.ptr(oq), 0, NS)
+            O.orc_decim_free(C.c_void_p(st))
+            if full:                                             # ... and the decoder thread's share (:284-317)
+                O.orc_normalise(ol.ptr(oi), ol.ptr(oq), C.c_int(n), C.c_int(NS))
+                ol.decode(oi, oq, NS)
+            return n
+        t0 = time.perf_counter()
+        one(False)
+        single = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            outs = list(ex.map(one, [False] * cores))
+        wall = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, [True] * cores))
+        wall_full = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cores / wall_full, "unit": "segments/s", "cores": cores, "kind": "port",
+                               "decimator_only_segments_per_s": cores / wall,
+                               "decimator_MBs_per_core_alone": RAW_BYTES / single / 1e6, "outputs_per_segment": int(outs[0]),
+                               "sample": "one 576 MB raw segment per host thread (%d threads) through oracle/liboracle.so: "
+                                         "orc_decim_feed (scalar C restatement of rtlsdr_callback, rtlsdr_wsprd.c:126-244; the "
+                                         "reference's README quotes this stage as its 'RX load'), then normalise + decode "
+                                         "(:284-317)" % cores}
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: re-executes this script as N ranks of ONE node under
     torch.distributed.run (one rank per GPU, RCCL over xGMI, rendezvous on 127.0.0.1), each rank with its share of
@@ -218,11 +280,14 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
                     help="BASELINE.json configs index: 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB, deep search "
                          "on; the headline: largest single-GPU configuration), 2 = configs[1] (1024 seg x 1 signal, "
-                         "-20 dB), 5 = configs[4] (raw 2.4 Msps u8 IQ through the on-GPU decimator; --segments raw "
-                         "segments resident per step, default 64)")
+                         "-20 dB), 5 = configs[4] (raw 2.4 Msps u8 IQ through the on-GPU decimator; --segments = segments "
+                         "per decoder call, default 1024, fed by front-end waves of --raw-segments)")
+    ap.add_argument("--raw-segments", type=int, default=64,
+                    help="--config 5: distinct raw segments resident in HBM (576 MB each) = one front-end wave")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
+    ap.add_argument("--no-tertiary", action="store_true", help="skip the configs[4] block of the N=1 line")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
     ap.add_argument("--fano-fast", type=int, default=None,
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
@@ -302,15 +367,22 @@ def main():
                 workload += ("; Fano attempts on the device (exact wave-parallel search) once the pipeline has seen the "
                              "band is crowded; before that the host pool with a budget of %d cycles/bit + device tail" % fast)
         else:
-            raw, expected = synth_raw_gpu(nseg, 777 + seed, dev, args.snr)
+            # configs[4]: `nraw` distinct raw segments stay resident (576 MB each); a step takes nseg / nraw front-end
+            # waves over them into the rows of an IQ ring (360 KB per segment) and ONE decoder call over the nseg rows,
+            # so the decoder works on configs[1]-sized batches while the raw data streams through wave after wave
+            nraw = min(args.raw_segments, nseg)
+            assert nseg % nraw == 0, "--segments must be a multiple of --raw-segments"
+            raw, exp_raw = synth_raw_gpu(nraw, 777 + seed, dev, args.snr)
+            expected = [exp_raw[i % nraw] for i in range(nseg)]
             stride = int(L.wspr_iq_stride())
             I = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
             Q = torch.zeros(nseg, stride, device=dev, dtype=torch.float32)
-            workload = ("configs[4]: %d raw segments per step (2.4 Msps u8 IQ, 576 MB each, resident in HBM) through the "
-                        "on-GPU decimator (K0) and the decoder; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's "
-                        "4096 segments = %d such resident waves" % (nseg, args.snr, 4096 // nseg))
+            workload = ("configs[4]: raw 2.4 Msps u8 IQ (576 MB per 2-minute segment, %d distinct segments resident in HBM) "
+                        "through the on-GPU decimator (K0) in waves of %d into an IQ ring, decoded %d segments per decoder "
+                        "call; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's 4096 segments = %d such steps"
+                        % (nraw, nraw, nseg, args.snr, max(1, 4096 // nseg)))
         torch.cuda.synchronize()
-        decs = [w.BatchDecoder(nseg, max_results=16 if config == 2 else 32, options=opt) for _ in range(inflight)]
+        decs = [w.BatchDecoder(nseg, max_results=16 if config != 3 else 32, options=opt) for _ in range(inflight)]
         gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
         if config == 5:                                  # the decimator's output rows, one set per lane
             IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
@@ -319,8 +391,11 @@ def main():
         def decode_on(k):
             if config == 5:
                 Ik, Qk = IQs[k]
-                rc = L.wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nseg, Ik.data_ptr(), Qk.data_ptr(), 1)
-                assert rc == 0
+                row = Ik.stride(0) * 4
+                for wv in range(nseg // nraw):
+                    rc = L.wspr_decimate_u8_batch_device(raw.data_ptr(), RAW_BYTES, nraw, Ik.data_ptr() + wv * nraw * row,
+                                                         Qk.data_ptr() + wv * nraw * row, 1)
+                    assert rc == 0
                 decs[k].decode_ptr(Ik.data_ptr(), Qk.data_ptr(), NS, Ik.stride(0))
             else:
                 decs[k].decode(I, Q)
@@ -384,7 +459,7 @@ def main():
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
                 "timings": timings}
 
-    nseg = args.segments or {2: 1024, 3: 8192, 5: 64}[args.config]
+    nseg = args.segments or {2: 1024, 3: 8192, 5: 1024}[args.config]
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
 
     fanout = None
@@ -476,28 +551,10 @@ def main():
             L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
             roof["measured_copy16_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9     # 16 bytes per lane
             del src, dst
-        if args.config == 5:
-            kms = (C.c_double * 1)()
-            # K0 alone, HIP events on the launch stream: 5 launches to settle, then three sets of 10; the sets come out
-            # bimodal on some boxes right after the decoder's load (6.1 or 7.3 ms per 64 segments, a whole set at a
-            # time, while tools/k0_scan.py on an idle GPU repeats 0.78 of peak every time), so all three are reported
-            # and the best one is the figure
-            L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 5, C.addressof(kms))
-            k0_sets = []
-            for _ in range(3):
-                L.wspr_bench_decimate(m["raw"].data_ptr(), RAW_BYTES, nseg, I.data_ptr(), Q.data_ptr(), 10, C.addressof(kms))
-                k0_sets.append(kms[0])
-            kms[0] = min(k0_sets)
-            k0_bytes = (RAW_BYTES + 360000) * nseg
-            rms = (C.c_double * 1)()
-            L.wspr_calib_read(m["raw"].data_ptr(), RAW_BYTES, nseg, 10, C.addressof(rms))
-            roof["front_end_K0"] = {"bound": "hbm", "avg_launch_ms": kms[0], "bytes_per_launch": k0_bytes,
-                                    "achieved_GBs": k0_bytes / (kms[0] * 1e-3) / 1e9,
-                                    "frac": k0_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "avg_launch_ms_of_each_set_of_10": k0_sets,
-                                    # the same rows read by a kernel with K0's access pattern and no arithmetic
-                                    "measured_read_GBs": RAW_BYTES * nseg / (rms[0] * 1e-3) / 1e9}
         cpu = None
+        if args.config == 5:
+            roof["front_end_K0"] = k0_report(L, m, world == 1 and not args.no_cpu_baseline)
+            cpu = roof["front_end_K0"].pop("cpu_baseline", None)
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             cnt = min(nseg, 512)
             Ih, Qh = I[:cnt].cpu().numpy(), Q[:cnt].cpu().numpy()
@@ -513,6 +570,19 @@ def main():
             secondary = {"workload": m2["workload"], "value": m2["value"], "unit": "segments/s", "steps": m2["steps"],
                          "ms_per_step": m2["ms_per_step"], "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
                          "false_decodes": m2["false_decodes"], "stage_ms_last_step": m2["timings"]}
+        tertiary = None
+        if world == 1 and args.config == 3 and not args.no_tertiary and not use_dist:
+            # configs[4] (raw 2.4 Msps input through the on-GPU decimator) rides along in the default line: its
+            # throughput, K0's roofline and the decimator's CPU baseline
+            m["I"] = m["Q"] = None
+            torch.cuda.empty_cache()
+            m3 = measure(5, 1024, 6, 2, rank)
+            tertiary = {"workload": m3["workload"], "value": m3["value"], "unit": "segments/s", "steps": m3["steps"],
+                        "ms_per_step": m3["ms_per_step"], "seconds_timed": m3["elapsed"], "decoded_ok": m3["decoded_ok"],
+                        "false_decodes": m3["false_decodes"], "stage_ms_last_step": m3["timings"],
+                        "front_end_K0": k0_report(L, m3, not args.no_cpu_baseline)}
+            del m3
+            torch.cuda.empty_cache()
         out = {
             "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
             "unit": "segments/s", "n_gpus": world, "steps": m["steps"], "warmup": args.warmup,
@@ -531,7 +601,8 @@ def main():
                                                          "step; counts: sum over its slots"),
             "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
-            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "fanout_check": fanout,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,
+            "fanout_check": fanout,
         }
     line = json.dumps(out) if rank == 0 else None
     if use_dist:

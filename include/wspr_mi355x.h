@@ -151,7 +151,8 @@ void wspr_shard_range(int nseg, int shard, int nshards, int *lo, int *hi);
 int wspr_decimate_u8(const uint8_t *iq, size_t nbytes, float *I, float *Q, uint32_t *n_out,
                      int normalise);
 /* nseg raw segments resident in HBM -> planar float IQ in HBM (rows of
- * wspr_iq_stride() floats), normalised, ready for wspr_decode_batch_device. */
+ * wspr_iq_stride() floats), normalised, ready for wspr_decode_batch_device.  d_raw and bytes_per_seg must be
+ * multiples of 16 (rows are read with aligned 16-byte loads); -1 otherwise. */
 int wspr_decimate_u8_batch_device(const void *d_raw, size_t bytes_per_seg, int nseg,
                                   void *d_idat, void *d_qdat, int normalise);
 
@@ -188,7 +189,9 @@ void wspr_front_end_constants(float *taps33, int *samples_per_output);
  * rtlsdr_wsprd.c:78-90), the decimator's static state (:135-160) and the body of its decoder thread (:263-328) as
  * one object.  The application keeps its three threads: the RX thread feeds librtlsdr callback buffers, the main
  * loop rolls the buffers over on the even minute, the decoder thread decodes the completed buffer.  feed() may
- * run beside decode() (they touch different buffers; the front end runs on its own lane of the library). */
+ * run beside decode(): feed() and rollover() exclude each other (a roll-over waits for the callback in flight, and
+ * nothing is written into a buffer once rollover() has returned its index), and the front end runs on a lane of
+ * the library that wspr_bind_thread_lane() never hands out. */
 typedef struct wspr_session wspr_session;
 wspr_session *wspr_session_create(struct decoder_options options);     /* initSampleStorage(), :331-336 */
 void wspr_session_destroy(wspr_session *s);
@@ -296,8 +299,8 @@ int wspr_device_count(void);
 int wspr_set_device(int device);
 /* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to four
  * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
- * this (returns the lane actually bound, 0..3); calls made from threads bound to different lanes may
- * overlap, e.g. to start the next batch under the tail of the current one. */
+ * this (returns the lane actually bound, 0..3; a fifth lane is reserved for receiver sessions); calls made from
+ * threads bound to different lanes may overlap, e.g. to start the next batch under the tail of the current one. */
 int wspr_bind_thread_lane(int lane);
 /* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
  * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with

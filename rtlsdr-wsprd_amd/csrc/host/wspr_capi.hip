@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -222,7 +223,7 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
     const char* virt = getenv("WSPR_NODE_VIRTUAL");      // test hook: more shards than devices, folded onto lanes
     const int per_dev = (ndevices + count - 1) / count;
     if ((ndevices > count && !(virt && atoi(virt))) || ndevices > Context::kMaxDevices ||
-        Context::lane() + per_dev > Context::kMaxLanes - 1) {
+        Context::lane() + per_dev > Context::kUserLanes) {
         fprintf(stderr, "libwspr_mi355x: wspr_decode_batch_node: %d devices asked for, %d visible\n", ndevices, count);
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return -1;
@@ -427,7 +428,8 @@ int wspr_set_device(int device) {
 }
 
 int wspr_bind_thread_lane(int lane) {
-    Context::bind_lane(lane);
+    // the last lane is the receiver sessions' (wspr_session_feed runs beside a decode): callers get 0..3
+    Context::bind_lane(lane < 0 ? 0 : (lane >= Context::kUserLanes ? Context::kUserLanes - 1 : lane));
     return Context::lane();
 }
 
@@ -469,6 +471,12 @@ int wspr_calib_read(const void* d_raw, size_t bytes_per_seg, int nseg, int iters
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {
     try {
+        // rows are read with aligned 16-byte vector loads (a misaligned row stride would also let the last vector of
+        // the last row run past the caller's allocation)
+        if ((bytes_per_seg & 15) || (reinterpret_cast<uintptr_t>(d_raw) & 15)) {
+            fprintf(stderr, "libwspr_mi355x: wspr_decimate_u8_batch_device: d_raw and bytes_per_seg must be multiples of 16\n");
+            return -1;
+        }
         return Context::get().decimate_device(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, normalise, nullptr);
     } catch (const std::exception& e) { return fail("wspr_decimate_u8_batch_device", e); }
 }
@@ -528,6 +536,11 @@ struct wspr_session {
     std::vector<float> I[2], Q[2];
     std::atomic<uint32_t> fill[2];
     std::atomic<uint32_t> active;
+    // feed() holds it from reading `active` to committing the new fill, rollover() takes it: a roll-over waits for
+    // the callback in flight (the reference tests bufferIndex per output sample, rtlsdr_wsprd.c:236-242, so its
+    // window is one sample; a GPU round trip must not straddle the switch), and no feed can write into a buffer
+    // after rollover() has handed it to the decoder thread.
+    std::mutex feed_mu;
 };
 
 namespace {
@@ -557,6 +570,7 @@ void wspr_session_destroy(wspr_session* s) { delete s; }
 int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
     if (!s || !buf || (len & 15u)) return -1;
     const int caller_lane = Context::lane();
+    std::lock_guard<std::mutex> hold(s->feed_mu);
     try {
         Context::bind_lane(kFrontEndLane);
         const uint32_t idx = s->active.load();
@@ -575,6 +589,7 @@ int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
 
 int wspr_session_rollover(wspr_session* s) {
     if (!s) return -1;
+    std::lock_guard<std::mutex> hold(s->feed_mu);            // not while a callback's outputs are still on their way
     const uint32_t prev = s->active.load(), next = prev ^ 1u;
     s->fill[next].store(0);                                 // rx_state.iqIndex[rx_state.bufferIndex] = 0
     s->active.store(next);

@@ -50,7 +50,8 @@ public:
     static Context& get();          // slot 0; throws std::runtime_error when no HIP device is usable
     static Context& slot(int i);    // i in [0, slots())
     static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
-    static constexpr int kMaxLanes = 4;
+    static constexpr int kMaxLanes = 5;          // lanes 0..3 for callers, the last one for receiver sessions (feed)
+    static constexpr int kUserLanes = kMaxLanes - 1;
     static constexpr int kMaxDevices = 16;
     static int lane();              // lane of the calling thread
     static void bind_lane(int lane);

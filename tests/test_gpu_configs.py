@@ -282,6 +282,80 @@ def test_receiver_session_two_minute_flow(env):
     L.wspr_session_destroy(s)
 
 
+def test_receiver_session_rollover_during_a_feed(env):
+    """Round-2 advisor finding: feed() read `active`, ran a GPU round trip, then committed into that buffer -- a
+    roll-over (and the decoder's in-place normalisation) in between corrupted the completed slot.  Now feed() and
+    rollover() exclude each other.  An RX thread feeds 600 callbacks while the main thread rolls the buffers over
+    four times at arbitrary moments and reads the completed buffer at once: every completed buffer must hold exactly
+    the next run of the oracle's output stream (whole callbacks, nothing lost, nothing written after the hand-over),
+    and a thread may not bind the sessions' lane."""
+    import threading
+    import time
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_rollover.argtypes = [C.c_void_p]
+    L.wspr_session_fill.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_session_fill.restype = C.c_uint32
+    L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.wspr_session_samples.restype = C.POINTER(C.c_float)
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    assert L.wspr_bind_thread_lane(7) == 3 and L.wspr_bind_thread_lane(0) == 0      # lane 4 is the sessions'
+    CB, NCB = 65536, 600
+    rng = np.random.default_rng(99)
+    host = rng.integers(0, 256, CB * NCB, dtype=np.uint8)
+    O = ol.lib()
+    ost = O.orc_decim_new()
+    oi, oq = np.zeros(NS, np.float32), np.zeros(NS, np.float32)
+    nout = O.orc_decim_feed(C.c_void_p(ost), ol.ptr(host), host.size, ol.ptr(oi), ol.ptr(oq), 0, NS)
+    O.orc_decim_free(C.c_void_p(ost))
+    s = L.wspr_session_create(w.default_options())
+    errs = []
+
+    def rx():
+        for k in range(NCB):
+            chunk = np.ascontiguousarray(host[k * CB:(k + 1) * CB])
+            if L.wspr_session_feed(s, ol.ptr(chunk), chunk.size) < 0:
+                errs.append(k)
+    t = threading.Thread(target=rx)
+    t.start()
+    pieces = []
+    for _ in range(4):
+        time.sleep(0.04)
+        done = L.wspr_session_rollover(s)
+        n = L.wspr_session_fill(s, done)
+        gi = np.ctypeslib.as_array(L.wspr_session_samples(s, done, 0), shape=(NS,))[:n].copy()
+        gq = np.ctypeslib.as_array(L.wspr_session_samples(s, done, 1), shape=(NS,))[:n].copy()
+        time.sleep(0.01)                                     # a late write into the handed-over buffer would show here
+        assert L.wspr_session_fill(s, done) == n
+        assert np.array_equal(np.ctypeslib.as_array(L.wspr_session_samples(s, done, 0), shape=(NS,))[:n], gi)
+        pieces.append((gi, gq))
+    t.join()
+    done = L.wspr_session_rollover(s)
+    n = L.wspr_session_fill(s, done)
+    pieces.append((np.ctypeslib.as_array(L.wspr_session_samples(s, done, 0), shape=(NS,))[:n].copy(),
+                   np.ctypeslib.as_array(L.wspr_session_samples(s, done, 1), shape=(NS,))[:n].copy()))
+    L.wspr_session_destroy(s)
+    assert not errs
+    gi = np.concatenate([p[0] for p in pieces]); gq = np.concatenate([p[1] for p in pieces])
+    assert gi.size == nout and nout == CB * NCB // 2 // 6401
+    assert np.array_equal(gi, oi[:nout]) and np.array_equal(gq, oq[:nout])
+    assert sum(1 for p in pieces if p[0].size) >= 2          # the roll-overs really fell inside the stream
+
+
+def test_batch_decimator_rejects_misaligned_rows(env):
+    torch, bench, w, dev = env
+    raw = torch.zeros(2 * 12802 * 4 + 64, device=dev, dtype=torch.uint8)
+    I = torch.zeros(2, int(w.lib().wspr_iq_stride()), device=dev); Q = torch.zeros_like(I)
+    w.sync_torch()
+    L = w.lib()
+    assert L.wspr_decimate_u8_batch_device(raw.data_ptr(), 12802 * 4, 2, I.data_ptr(), Q.data_ptr(), 0) == -1     # 51208 % 16 = 8
+    assert L.wspr_decimate_u8_batch_device(raw.data_ptr() + 8, 12800 * 4, 2, I.data_ptr(), Q.data_ptr(), 0) == -1
+    assert L.wspr_decimate_u8_batch_device(raw.data_ptr(), 12800 * 4, 2, I.data_ptr(), Q.data_ptr(), 0) == 0
+
+
 # ------------------------------------------------------------------ calibration hooks behind the rooflines
 def test_calibration_hooks_report_plausible_ceilings(env):
     """The three ceilings bench.py prints beside the rooflines come from kernels of the library itself: a stream copy

