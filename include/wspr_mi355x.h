@@ -277,16 +277,12 @@ int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int sa
  * launch set). */
 int wspr_bench_valu(const void *d_idat, const void *d_qdat, int nseg, int samples, size_t seg_stride,
                     int iters, double *ms);
-/* Device Fano search (K6) over n soft-symbol vectors of 162 bytes in transmission
+/* Device Fano search (K6w) over n soft-symbol vectors of 162 bytes in transmission
  * (interleaved) order, i.e. deinterleave() + fano() of reference wsprd.c:759-761 (fano.c:87-238) with
- * delta 60.  Outputs per vector: ret (0 / -1), cycles, metric, maxnp, data[10].
- * wspr_fano_batch_device: the serial walk, one GPU lane per vector (every output as the reference's).
- * wspr_fano_batch_device_wave: the wave-parallel search the decoder's tail uses, one wavefront per vector
- * (fano_wave.h): ret, cycles and data are the reference's; metric/maxnp are filled for decoded frames
- * only (the reference's caller reads nothing else of a failed attempt, wsprd.c:759-766).  steps (may be
- * NULL): expansion steps per vector. */
-int wspr_fano_batch_device(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
-                           unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data);
+ * delta 60: the exact wave-parallel search the decoder uses, one wavefront per vector (fano_wave.h).  Outputs per
+ * vector: ret (0 / -1), cycles and data[10] are the reference's; metric/maxnp are filled for decoded frames only
+ * (the reference's caller reads nothing else of a failed attempt, wsprd.c:759-766).  steps (may be NULL):
+ * expansion steps per vector. */
 int wspr_fano_batch_device_wave(const unsigned char *symbols, int n, unsigned maxcycles, int *ret,
                                 unsigned *cycles, unsigned *metric, unsigned *maxnp, unsigned char *data,
                                 unsigned *steps);

@@ -441,17 +441,10 @@ int wspr_set_fano_device_mode(int mode) {
     return wspr::fano_device_setting().exchange(mode < 0 ? -1 : (mode ? 1 : 0));
 }
 
-int wspr_fano_batch_device(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
-                           unsigned* metric, unsigned* maxnp, unsigned char* data) {
-    try {
-        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, true);
-    } catch (const std::exception& e) { return fail("wspr_fano_batch_device", e); }
-}
-
 int wspr_fano_batch_device_wave(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
                                 unsigned* metric, unsigned* maxnp, unsigned char* data, unsigned* steps) {
     try {
-        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, false, steps);
+        return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, steps);
     } catch (const std::exception& e) { return fail("wspr_fano_batch_device_wave", e); }
 }
 

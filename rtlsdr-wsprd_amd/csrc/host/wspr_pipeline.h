@@ -101,11 +101,9 @@ public:
     void subtract_single(float* id, float* qd, long np, float f0, int shift, float drift, const unsigned char* sym);
     void subtract_symbolwise_single(float* id, float* qd, long np, float f0, int shift, float drift,
                                     const unsigned char* sym);
-    // serial_lanes: the one-lane-per-vector kernel (k6_fano_tail.hip; also fills metric/maxnp of time-outs)
-    // instead of the wave-parallel search (k6_fano_wave.hip); steps (may be null): expansion steps per vector
+    // the wave-parallel search (k6_fano_wave.hip) over host vectors; steps (may be null): expansion steps per vector
     int fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
-                   unsigned* metric, unsigned* maxnp, unsigned char* data, bool serial_lanes = false,
-                   unsigned* steps = nullptr);
+                   unsigned* metric, unsigned* maxnp, unsigned char* data, unsigned* steps = nullptr);
     int fano_resident(const unsigned char* d_symbols, const int* h_offsets, int n, unsigned maxcycles, int* ret,
                       unsigned* cycles, unsigned char* data);
     int bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters, double* ms);

@@ -649,9 +649,7 @@ struct Context::DecodeRun {
     std::vector<ItemTrace> wtrace;
 
     // one Fano attempt on a soft-symbol vector in transmission order (wsprd.c:759-761)
-    // ladder = an attempt on rungs 1..42 (those rarely decode: with the budget split on they get the shorter
-    // host budget `fast_ladder` before they are left to the device tail)
-    int fano_attempt(const unsigned char* tx_sym, unsigned* cycles, unsigned char* data11, bool ladder = false) const {
+    int fano_attempt(const unsigned char* tx_sym, unsigned* cycles, unsigned char* data11) const {
         memset(data11, 0, 11);
         if (memo)
             if (const FanoMemo::Entry* e = memo->find(tx_sym)) {
@@ -663,8 +661,7 @@ struct Context::DecodeRun {
         memcpy(sym, tx_sym, kNSymD);
         deinterleave162(sym);
         unsigned metric, maxnp;
-        return fano_decode(&metric, cycles, &maxnp, data11, sym, kNBits, met.tab, delta,
-                           (ladder && fast) ? std::min(maxcycles, fast_ladder) : maxcycles);
+        return fano_decode(&metric, cycles, &maxnp, data11, sym, kNBits, met.tab, delta, maxcycles);
     }
 
     // tuning constants of wsprd.c:423-433
@@ -674,7 +671,6 @@ struct Context::DecodeRun {
     const float minrms = 52.0 * (50 / 64.0);
     const int delta = 60;
     const unsigned maxcycles;
-    const unsigned fast_ladder = [] { const char* e = getenv("WSPR_FANO_FAST_LADDER"); return e ? (unsigned)atoi(e) : 10000u; }();
     const int lagstep, nlag0, njit_rest;
     const FanoMetrics& met = default_metrics();
 
@@ -1078,7 +1074,7 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
             if (r > first[a].load()) return;           // an earlier rung already decoded
             const size_t g = (size_t)a * kMaxLags + (size_t)((c.jitter_ladder[r + 1] + 63) / 3);
             if (!(h_sync[g] > minsync2 && h_rms[g] > minrms)) return;
-            const int nd = fano_attempt(h_sym + g * kNSymD, &at.cycles, at.data, true);
+            const int nd = fano_attempt(h_sym + g * kNSymD, &at.cycles, at.data);
             at.pending = (nd != 0) && fast;
             if (!at.pending) { c.n_fano++; c.n_cycles += at.cycles; if (nd) c.n_timeout++; }
             if (nd == 0) {
@@ -1464,7 +1460,7 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
 // kernel reports -2 for a vector whose pending-visit store overflowed (not seen in tests; the serial host
 // decoder takes those).
 int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
-                        unsigned* metric, unsigned* maxnp, unsigned char* data, bool serial_lanes, unsigned* steps) {
+                        unsigned* metric, unsigned* maxnp, unsigned char* data, unsigned* steps) {
     Impl& c = *d;
     if (n <= 0) return 0;
     int* h_off = static_cast<int*>(c.h_misc.need((size_t)n * 4));
@@ -1479,11 +1475,8 @@ int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles,
     unsigned* dsteps = steps ? static_cast<unsigned*>(c.fz_steps.need((size_t)n * 4)) : nullptr;
     upload(dsym, symbols, (size_t)n * kNSymD, c.stream);
     upload(doff, h_off, (size_t)n * 4, c.stream);
-    if (serial_lanes)
-        launch_fano_tail(dsym, doff, n, c.t_metric0.as<short>(), 60, maxcycles, dret, dcyc, dmet, dmax, ddat, c.stream);
-    else
-        launch_fano_wave(dsym, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, dmet, dmax, ddat, dsteps,
-                         static_cast<uint32_t*>(c.fz_pool.need(fano_wave_scratch_words(n) * 4)), c.stream);
+    launch_fano_wave(dsym, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, dmet, dmax, ddat, dsteps,
+                     static_cast<uint32_t*>(c.fz_pool.need(fano_wave_scratch_words(n) * 4)), c.stream);
     HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     HIP_OK(hipMemcpyAsync(metric, dmet, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
@@ -1491,7 +1484,7 @@ int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles,
     HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
     if (steps) HIP_OK(hipMemcpyAsync(steps, dsteps, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     sync();
-    if (!serial_lanes) {
+    {
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) if (ret[i] == -2) redo.push_back(i);
         if (!redo.empty()) {

@@ -29,7 +29,7 @@
 // exactly the reference's cycle count.  Visits after a found success are dropped.
 //
 // A time-out of 810 000 cycles takes about 8 700 steps of 64 visits instead of 810 000 serial
-// iterations (tests/test_fano_wave.py; the serial forms stay in fano_stateless.h / wspr_message.cpp).
+// iterations (tests/test_fano_wave.py; the serial form is the host routine in wspr_message.cpp).
 #pragma once
 #include <stdint.h>
 

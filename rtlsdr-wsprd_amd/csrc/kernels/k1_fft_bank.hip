@@ -400,23 +400,16 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
                      int samples, float* ps, const DeviceTables& t, hipStream_t st) {
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (blocks <= 0 || nseg_active <= 0) return;
-    // consecutive FFTs per wave: 4 (a workgroup covers 16 time blocks: 64-byte row segments, 47 KB of LDS,
-    // three workgroups per CU; measured 259 us per 1024 segments) or 8 (32 time blocks: 128-byte segments,
-    // 73 KB, two per CU; 282 us)
-    static const int run = [] { const char* e = getenv("WSPR_K1_RUN"); return e ? atoi(e) : 4; }();
-#define WSPR_K1(R)                                                                                          \
-    do {                                                                                                    \
-        const int per_wg = R * kWavesPerWg;                                                                 \
-        const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (per_wg + 1) * sizeof(float); \
-        static std::atomic<unsigned> opted{0};                                                              \
-        lds_opt_in(reinterpret_cast<const void*>(&fft_bank_kernel<R>), lds, opted);                         \
-        dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);                                             \
-        hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), lds, st, dI, dQ, seg_list, blocks, ps,      \
-                           t.window, t.twiddle);                                                            \
-    } while (0)
-    if (run == 8) WSPR_K1(8);
-    else WSPR_K1(4);
-#undef WSPR_K1
+    // four consecutive FFTs per wave: a workgroup covers 16 time blocks (64-byte row segments, 47 KB of LDS, three
+    // workgroups per CU).  Eight per wave (128-byte segments, 73 KB, two per CU) measured slower: 282 vs 259 us per
+    // 1024 segments.
+    constexpr int R = 4;
+    constexpr int per_wg = R * kWavesPerWg;
+    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (per_wg + 1) * sizeof(float);
+    static std::atomic<unsigned> opted{0};
+    lds_opt_in(reinterpret_cast<const void*>(&fft_bank_kernel<R>), lds, opted);
+    dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);
+    hipLaunchKernelGGL(fft_bank_kernel<R>, grid, dim3(256), lds, st, dI, dQ, seg_list, blocks, ps, t.window, t.twiddle);
 }
 
 // K1 + K2a in one kernel (see fft_bank_avg_kernel); one workgroup per segment, so only for batches that

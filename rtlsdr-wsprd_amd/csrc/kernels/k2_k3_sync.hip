@@ -625,7 +625,7 @@ void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, i
         for (int k = 0; k < kNSymD; ++k) if (pr3[k]) b.w[k >> 5] |= 1u << (k & 31);
         return b;
     }();
-    static const int gy = [] { const char* e = getenv("WSPR_K3_GRID_Y"); return e ? atoi(e) : 16; }();
+    constexpr int gy = 16;                                   // candidate pairs in flight per segment
     // Full-length records of large batches take the lane-per-(candidate, lag) kernel: its single-wave workgroups
     // pay two staging round trips each, which a launch of a few hundred candidate pairs cannot hide (1 024
     // single-signal segments: 59 vs 46 us; 8 192 x 10 signals: 0.93 vs 1.15 ms).  WSPR_K3_KERNEL=waves / lane force one.

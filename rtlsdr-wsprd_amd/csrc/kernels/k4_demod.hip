@@ -257,8 +257,7 @@ template <int STEP, bool SHARED>
 __global__ __launch_bounds__(448)
 void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list, int mode,
-                       int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out,
-                       int scalar_table) {
+                       int nlag, float minsync1, const float* __restrict__ tabs, float4* __restrict__ pw_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int item = item_list[blockIdx.y];
     const FineState st = items[item];
@@ -267,7 +266,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const int i0 = blockIdx.x * kTileSyms, tid = threadIdx.x;
     const int lag0 = (mode == 0) ? st.shift_coarse - 128 : st.shift - 63;
     float4* tab = reinterpret_cast<float4*>(smem);
-    float2* tile = reinterpret_cast<float2*>(smem + (SHARED ? 8192 : kTileSyms * kOwnTabPitch * 16));
+    float2* tile = reinterpret_cast<float2*>(smem + (SHARED ? 0 : kTileSyms * kOwnTabPitch * 16));
     const int span = kSps * kTileSyms + STEP * (nlag - 1);
     const int pitch = (span + STEP - 1) / STEP + 1;
 
@@ -277,20 +276,10 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const int nthr = blockDim.x;
     // the candidate's one table (built by phasor_table_kernel): every lane of the workgroup reads the same
     // entry at every step, so it is read through the scalar cache straight into SGPR operands of the packed
-    // multiplies (WSPR_K4_TABLE=lds restores the LDS copy: two 16-byte LDS reads per lane and step)
+    // multiplies (an LDS copy costs two 16-byte LDS reads per lane and step: 2.00 vs 1.91 ms per 2 048 candidates)
     const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
                                       (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
-    if constexpr (SHARED) {
-        if (!scalar_table) {
-            for (int e0 = tid; e0 < 512; e0 += 4 * nthr) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) v[u] = gtab[e]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int e = e0 + u * nthr; if (e < 512) tab[e] = v[u]; }
-            }
-        }
-    } else {
+    if constexpr (!SHARED) {
         // a drifting candidate has one table per symbol (162 x 8 KB): its 6 x 4 phasor recurrences are run
         // here by the first 24 lanes, straight into LDS, instead of travelling through HBM (2.6 MB per
         // candidate written and read back); same operations as phasor_table_kernel (wsprd.c:158-188)
@@ -338,7 +327,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
     if constexpr (STEP == 8 || STEP == 16) {
         // e = STEP*m + 256*il + j with STEP | 256: row = j % STEP, column = m + (256/STEP)*il + j/STEP
         const float2* __restrict__ col = tile + m + (kSps / STEP) * il;
-        if (SHARED && scalar_table) {
+        if (SHARED) {
             for (int j0 = 0; j0 < kSps; j0 += STEP) {
                 const float2* __restrict__ t0 = col + j0 / STEP;
 #pragma unroll
@@ -353,7 +342,7 @@ void demod_tile_kernel(const float* __restrict__ dI, const float* __restrict__ d
         }
     } else {
         const int e0 = STEP * m + kSps * il;
-        if (SHARED && scalar_table) {
+        if (SHARED) {
 #pragma unroll 8
             for (int j = 0; j < kSps; ++j) {
                 const int e = e0 + j;
@@ -729,66 +718,9 @@ void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restri
     }
 }
 
-// Workgroup = candidate, thread = (frequency hypothesis, symbol): 810 of 832 threads run one serial
-// 256-sample tone correlation each.  The five hypotheses share the samples (same lag), so the 162 x 32 chunk
-// is staged ONCE per workgroup (coalesced 128-byte row segments from HBM/L2, transposed so that thread =
-// symbol reads conflict-free) and serves all five; their phasor tables (5 x 8 KB) sit in LDS and a wave reads
-// them as a broadcast (a wave holds one hypothesis, two at a boundary).  The next chunk is in flight in
-// registers while the current one is consumed.  (Round 1 ran one workgroup per hypothesis: five times the
-// staging instructions and barriers for the same arithmetic -- 0.20 of the packed-pipe bound.)
-constexpr int kFsThreads = 832;                                   // 13 waves: 5 x 162 = 810 working threads
+constexpr int kFsThreads = 832;                                   // 13 waves: 5 x 162 = 810 working threads (freq_drift_kernel)
 constexpr int kFsChunk = 32;
 constexpr int kFsPerThread = (kNSymD * kFsChunk + kFsThreads - 1) / kFsThreads;      // 7 samples staged per thread and chunk
-
-__global__ __launch_bounds__(kFsThreads)
-void freq_tile_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                      const FineState* __restrict__ items, const int* __restrict__ item_list,
-                      const float* __restrict__ tabs, float4* __restrict__ pw_out) {
-    extern __shared__ __attribute__((aligned(16))) char fs_smem[];
-    float4* tab = reinterpret_cast<float4*>(fs_smem);                                   // [5][2 * 256]: (c0..c3), (s0..s3)
-    float2 (*tile)[kFsChunk + 1] = reinterpret_cast<float2 (*)[kFsChunk + 1]>(fs_smem + kNFreq * 2 * kSps * sizeof(float4));
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    const FineState st = items[item_list[slot]];
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * (2 * kSps);
-    for (int e = tid; e < kNFreq * 2 * kSps; e += kFsThreads) tab[e] = gt[e];
-    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
-    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int f = tid / kNSymD, sym = tid - f * kNSymD;
-    const bool working = f < kNFreq;
-    const float4* __restrict__ tb = tab + (working ? f : 0) * (2 * kSps);
-
-    float2 nxt[kFsPerThread];
-    auto fetch = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < kFsPerThread; ++u) {
-            const int e = u * kFsThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
-            const int k = st.shift + kSps * row + kFsChunk * c + col;
-            const bool ok = (e < kNSymD * kFsChunk) && (k > 0) && (k < np);
-            nxt[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
-        }
-    };
-    fetch(0);
-    ToneAcc acc;
-    acc.clear();
-    for (int c = 0; c < kSps / kFsChunk; ++c) {
-        __syncthreads();                                             // the previous chunk has been consumed
-#pragma unroll
-        for (int u = 0; u < kFsPerThread; ++u) {
-            const int e = u * kFsThreads + tid;
-            if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = nxt[u];
-        }
-        __syncthreads();
-        if (c + 1 < kSps / kFsChunk) fetch(c + 1);
-        if (working) {
-#pragma unroll 8
-            for (int jj = 0; jj < kFsChunk; ++jj) {
-                const int j = kFsChunk * c + jj;
-                acc.step(tile[sym][jj], tb[2 * j], tb[2 * j + 1]);
-            }
-        }
-    }
-    if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
-}
 
 // Scalar-table form of freq_tile_kernel: a hypothesis owns three whole waves (lane = symbol, 162 of 192 lanes),
 // so its one table is wave-uniform and is read through the scalar cache straight into SGPR operands of the packed
@@ -1063,17 +995,8 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     const float4* pl = reinterpret_cast<const float4*>(pw_lag);
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-        const size_t fs_lds = kNFreq * 2 * kSps * sizeof(float4) + (size_t)kNSymD * (kFsChunk + 1) * sizeof(float2);   // 83 KB
-        static std::atomic<unsigned> fs_opted{0};
-        static const bool lds_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return e && e[0] == 'l'; }();
-        if (!lds_tab)
-            hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
-                               list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_lag, lagstep);
-        else {
-            lds_opt_in(reinterpret_cast<const void*>(&freq_tile_kernel), fs_lds, fs_opted);
-            hipLaunchKernelGGL(freq_tile_kernel, dim3(n_shared), dim3(kFsThreads), fs_lds, st, dI, dQ,
-                               samples, items, list_shared, tabs, reinterpret_cast<float4*>(pw));
-        }
+        hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
+                           list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_lag, lagstep);
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
                            reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
                            sync_out, sym_out, rms_out, t.sync);
@@ -1119,7 +1042,6 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     };
     auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
-    static const int scalar_tab = [] { const char* e = getenv("WSPR_K4_TABLE"); return (e && e[0] == 'l') ? 0 : 1; }();
     // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one symbol per lane)
     static const bool lag3_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
     static std::atomic<unsigned> l3_opted{0};
@@ -1134,15 +1056,15 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                                tabs, pw4);                                                                       \
         else if (n_shared > 0)                                                                                   \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
-                               threads(kTileSymsShared), 8192 + tile_bytes(kTileSymsShared), st, dI, dQ, samples, \
-                               items, list_shared, mode, nlag, minsync1, tabs, pw4, scalar_tab);                 \
+                               threads(kTileSymsShared), tile_bytes(kTileSymsShared), st, dI, dQ, samples,        \
+                               items, list_shared, mode, nlag, minsync1, tabs, pw4);                             \
         if (n_own > 0 && STEP == 8 && nlag == 33 && mode == 0 && drift_kernel)                                   \
             hipLaunchKernelGGL(demod_drift_kernel, dim3((kNSymD + kDrSyms - 1) / kDrSyms, n_own), dim3(64), 0, st, \
                                dI, dQ, samples, items, list_own, pw4);                                           \
         else if (n_own > 0)                                                                                      \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, false>), dim3(kNSymD / kTileSymsOwn, n_own),             \
                                threads(kTileSymsOwn), kTileSymsOwn * kOwnTabPitch * 16 + tile_bytes(kTileSymsOwn), st, dI, dQ, \
-                               samples, items, list_own, mode, nlag, minsync1, tabs, pw4, 0);                    \
+                               samples, items, list_own, mode, nlag, minsync1, tabs, pw4);                       \
     } while (0)
     if (lagstep == 8) WSPR_LAUNCH_TILE(8);
     else if (lagstep == 16) WSPR_LAUNCH_TILE(16);

@@ -5,7 +5,7 @@
 // pre-order traversal of a tree of (node, threshold) visits; this kernel expands that tree 64
 // visits at a time from a stack kept in walk order, with per-visit ledgers that make the
 // reference's cycle count come out exactly.  An undecodable vector (810 000 cycles in the
-// reference, ~5 ms of a CPU core, 0.5 s of one GPU lane in the serial kernel k6_fano_tail.hip)
+// reference, ~5 ms of a CPU core; a serial walk on one GPU lane takes 0.5 s)
 // takes ~7 400 steps here (10 ms alone; 6 000 of them together: 18 ms).
 //
 // Per step (one wave, no divergence outside the three predicated store slots):

@@ -46,45 +46,8 @@ __device__ __forceinline__ float dphi_of_symbol(float f0, float drift, int i, un
     return (float)(kTwoPiDt * arg);
 }
 
-// lane = job: the run decomposition of the serial float phase walk.  The wave first copies its 64 job
-// records into LDS with coalesced, independent loads (a per-job loop of dependent global loads cost
-// 0.3 ms here), each lane then derives its job's 162 increments (double precision, no divergence) and
-// walks its runs in a flat loop of integer work that touches no global memory but its own stores.
-static_assert(sizeof(SubJob) % 4 == 0, "SubJob is copied as dwords");
-constexpr int kJobWords = (int)(sizeof(SubJob) / 4);               // 45: an odd LDS stride, conflict-free per lane
-__global__ __launch_bounds__(64)
-void sub_runs_kernel(const SubJob* __restrict__ jobs, int njobs, PhaseTable* __restrict__ tables) {
-    __shared__ unsigned raw[64 * kJobWords];
-    __shared__ float dph[64][kNSymD + 1];
-    const int lane = threadIdx.x, job0 = blockIdx.x * 64;
-    const int nwords = min(64, njobs - job0) * kJobWords;
-    const unsigned* __restrict__ g = reinterpret_cast<const unsigned*>(jobs + job0);
-    for (int e0 = 0; e0 < nwords; e0 += 64 * 9) {
-        unsigned v[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) { const int e = e0 + 64 * u + lane; v[u] = e < nwords ? g[e] : 0u; }
-#pragma unroll
-        for (int u = 0; u < 9; ++u) { const int e = e0 + 64 * u + lane; if (e < nwords) raw[e] = v[u]; }
-    }
-    __syncthreads();
-    const int job = job0 + lane;
-    if (job >= njobs) return;
-    const SubJob* jb = reinterpret_cast<const SubJob*>(raw) + lane;
-    PhaseTable& tb = tables[job];
-    const float f0 = jb->f0, drift = jb->drift;
-    float* d = dph[lane];
-    for (int i = 0; i < kNSymD; ++i) {
-        const float v = dphi_of_symbol(f0, drift, i, jb->sym[i]);
-        d[i] = v;
-        tb.dphi[i] = v;
-    }
-    const int nr = phase_runs_build([&](int i) { return d[i]; }, kNSymD, kSps, tb.runs, kPhaseMaxRuns, tb.first_run,
-                                    tb.sym_phi);
-    if (nr < 0) tb.first_run[0] = 0xffffu;
-}
-
-// The same tables with one WAVE per job (phase_runs_build_chained, phase_runs.h): up to 64 symbols are probed at
-// once, the leading ones whose 256 additions are all regular become one run each with prefix-summed
+// The run decomposition of the serial float phase walk, one WAVE per job (phase_runs_build_chained, phase_runs.h):
+// up to 64 symbols are probed at once, the leading ones whose 256 additions are all regular become one run each with prefix-summed
 // significands, the first that is not (a binade crossing, typically) is walked run by run; ~20 rounds per
 // signal instead of ~200-350 serial trips, and a thousand jobs are a thousand waves instead of sixteen
 // (0.34-0.43 ms of latency per launch with lane = job, during which the GPU held 16 waves).
@@ -219,75 +182,9 @@ void sub_ref_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, 
 }
 
 constexpr int kFirThreads = 256;
-constexpr int kFirPerLane = 4;
-constexpr int kFirOut = kFirThreads * kFirPerLane;             // 1024 outputs per workgroup
-constexpr int kFirSpan = kFirOut + kLpfTaps - 1;               // 1383 inputs
-constexpr int kFirPitch = (kFirSpan + 3) / 4 + 1;              // transposed-by-4 row pitch
-
-__global__ __launch_bounds__(kFirThreads)
-void sub_filter_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
-                       const SubJob* __restrict__ jobs, const float* __restrict__ perjob,
-                       const float* __restrict__ lpf, const float* __restrict__ lpf_part) {
-    __shared__ float2 tile[4 * kFirPitch];
-    __shared__ float w[kLpfTaps];
-    const int tid = threadIdx.x;
-    const SubJob* job = jobs + blockIdx.y;
-    const float2* __restrict__ ref = reinterpret_cast<const float2*>(perjob + (size_t)blockIdx.y * kSubPerJob);
-    const float2* __restrict__ cc = ref + kSigLen;
-    const int n0 = blockIdx.x * kFirOut;
-
-    // the reference filters a zero-padded copy (360 leading zeros); outside the signal the
-    // products are zero and adding them is exact
-    for (int e = tid; e < kFirSpan; e += kFirThreads) {
-        const int n = n0 - kLpfTaps / 2 + e;
-        const bool in = (n >= 0) && (n < kSigLen);
-        tile[(e & 3) * kFirPitch + (e >> 2)] = in ? cc[n] : make_float2(0.0f, 0.0f);
-    }
-    for (int e = tid; e < kLpfTaps; e += kFirThreads) w[e] = lpf[e];
-    __syncthreads();
-
-    // outputs n0 + 4*tid + r, r = 0..3; input index of tap j for output r: 4*tid + r + j
-    float si[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float2 x[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = tile[r * kFirPitch + tid];            // e = 4*tid + r
-#pragma unroll 4
-    for (int j = 0; j < kLpfTaps; ++j) {
-        const float wj = w[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = wj * x[r].x, b = wj * x[r].y;
-            si[r] = si[r] + a;
-            sq[r] = sq[r] + b;
-        }
-        x[0] = x[1]; x[1] = x[2]; x[2] = x[3];
-        const int e = 4 * tid + j + 4;                                       // next input of output 3
-        x[3] = tile[(e & 3) * kFirPitch + (e >> 2)];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 4 * tid + r;
-        if (n >= kSigLen) break;
-        float norm = 1.0f;                                   // wsprd.c:397-404
-        if (n < kLpfTaps / 2)                    norm = lpf_part[kLpfTaps / 2 + n];
-        else if (n > kSigLen - 1 - kLpfTaps / 2) norm = lpf_part[kLpfTaps / 2 + kSigLen - 1 - n];
-        const int k = job->shift + n;
-        if (k > 0 && k < np) {
-            float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
-            float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
-            const float2 rr = ref[n];
-            const float a = si[r] * rr.x, b = sq[r] * rr.y, c = si[r] * rr.y, d = sq[r] * rr.x;
-            const float ri = a - b, rq = c + d;
-            xi[k] = xi[k] - ri / norm;
-            xq[k] = xq[k] - rq / norm;
-        }
-    }
-}
-
-// Eight outputs per lane, taps from scalar registers.  In the kernel above a lane's four outputs share each
-// freshly read sample and the taps come from LDS: per four taps a wave issues 32 packed multiply/adds against
-// one 16-byte and four 8-byte LDS reads, and with four SIMDs on one LDS the return path is ~75 % busy.  Here a
-// lane slides an eight-sample register window (16 packed instructions per 8-byte LDS read) and the taps, the
+// Eight outputs per lane, taps from scalar registers.  (With four outputs per lane and the taps in LDS a wave
+// issued 32 packed multiply/adds per four taps against one 16-byte and four 8-byte LDS reads, and with four SIMDs
+// on one LDS the return path was ~75 % busy: 1.22 vs 0.95 ms per 1024 jobs.)  A lane slides an eight-sample register window (16 packed instructions per 8-byte LDS read) and the taps, the
 // same for every lane, arrive through the scalar cache eight at a time, issued a stage (eight taps = 128
 // packed instructions) before they are needed and waited for when a stage old (see demod_lag3_kernel).  The
 // tile is stored transposed by 8, so the per-tap read of consecutive lanes is consecutive 8-byte words.
@@ -483,21 +380,10 @@ void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int 
     if (njobs <= 0) return;
     float* perjob = scratch;
     PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch + (size_t)njobs * kSubPerJob);
-    // WSPR_K7_RUNS=lane: the lane-per-job run builder
-    static const bool runs_lane = [] { const char* e = getenv("WSPR_K7_RUNS"); return e && e[0] == 'l'; }();
-    if (runs_lane)
-        hipLaunchKernelGGL(sub_runs_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, tables);
-    else
-        hipLaunchKernelGGL(sub_runs_wave_kernel, dim3(njobs), dim3(64), 0, st, jobs, njobs, tables);
+    hipLaunchKernelGGL(sub_runs_wave_kernel, dim3(njobs), dim3(64), 0, st, jobs, njobs, tables);
     hipLaunchKernelGGL(sub_ref_kernel, dim3(kNSymD / kSymPerWg, njobs), dim3(256), 0, st, dI, dQ, samples, jobs, tables, perjob);
-    // WSPR_K7_FIR=4: the four-outputs-per-lane kernel with the taps in LDS
-    static const bool fir4 = [] { const char* e = getenv("WSPR_K7_FIR"); return e && e[0] == '4'; }();
-    if (fir4)
-        hipLaunchKernelGGL(sub_filter_kernel, dim3((kSigLen + kFirOut - 1) / kFirOut, njobs), dim3(kFirThreads), 0, st,
-                           dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
-    else
-        hipLaunchKernelGGL(sub_filter8_kernel, dim3((kSigLen + kFir8Out - 1) / kFir8Out, njobs), dim3(kFirThreads), 0, st,
-                           dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
+    hipLaunchKernelGGL(sub_filter8_kernel, dim3((kSigLen + kFir8Out - 1) / kFir8Out, njobs), dim3(kFirThreads), 0, st,
+                       dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
 }
 
 // Working copy of resident input: rows of `samples` floats (16-byte aligned, stride a multiple of 4) into

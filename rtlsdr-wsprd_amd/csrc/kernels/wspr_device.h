@@ -144,12 +144,9 @@ void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int 
 // subtract_signal() of the reference (wsprd.c:263-312): one segment row, symbols in device memory
 void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int shift, float drift,
                                 const unsigned char* d_sym, hipStream_t st);
-// Device Fano search (K6) for n soft-symbol vectors symbols[offsets[i]*162 ...] (interleaved order, as
-// the demodulator writes them); metric0 = the 256-entry "sent 0" branch-metric row.
-void launch_fano_tail(const unsigned char* symbols, const int* offsets, int n, const short* metric0, int delta,
-                      unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
-                      unsigned char* data, hipStream_t st);
-// Device Fano search, one wavefront per vector, 64 tree visits per step (k6_fano_wave.hip): exact return
+// Device Fano search (K6) for n soft-symbol vectors symbols[offsets[i]*162 ...] (interleaved order, as the
+// demodulator writes them); metric0 = the 256-entry "sent 0" branch-metric row.
+// One wavefront per vector, 64 tree visits per step (k6_fano_wave.hip): exact return
 // code, cycle count and decoded bytes; metric/maxnp only for decoded frames.  ret -2 = the wave's
 // pending-visit store overflowed (the caller decodes that vector some other way).  steps may be null.
 // scratch: fano_wave_scratch_words(n) words of device memory (the waves' pending-visit stores), or null for the

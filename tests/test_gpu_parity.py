@@ -587,45 +587,6 @@ def _oopt(use):
 
 
 # ------------------------------------------------------------------ K6 device Fano
-def test_device_fano_equals_host_fano(w):
-    """K6: deinterleave + Fano search on the GPU == the host routine (ret, cycles, metric, maxnp, bytes),
-    for decodable vectors, early time-outs and full 810 000-cycle time-outs."""
-    import time
-    L = w.lib()
-    rng = np.random.default_rng(8)
-    mt = (C.c_int * 256 * 2)(); L.wspr_fano_metric_table(mt)
-    enc = (C.c_ubyte * 176)()
-    vecs = []
-    for t in range(300):
-        data = [int(x) for x in rng.integers(0, 256, 7)] + [0, 0, 0, 0]
-        data[6] &= 0xC0
-        L.encode(enc, (C.c_ubyte * 11)(*data), C.c_uint(11))
-        bits = (C.c_ubyte * 162)(*list(enc)[:162])
-        L.interleave(bits)                                   # transmission order, as the demodulator emits
-        sigma = [5, 25, 40, 50, 60, 75, 100, 150][t % 8]
-        vecs.append(np.clip(np.where(np.frombuffer(bits, np.uint8) > 0, 178, 78) + rng.normal(0, sigma, 162), 0, 255).astype(np.uint8))
-    sym = np.stack(vecs)
-    for maxcycles in (200, 10000):
-        n = sym.shape[0]
-        ret = np.zeros(n, np.int32); cyc = np.zeros(n, np.uint32); met = np.zeros(n, np.uint32); mnp = np.zeros(n, np.uint32)
-        dat = np.zeros((n, 10), np.uint8)
-        t0 = time.time()
-        assert L.wspr_fano_batch_device(ol.ptr(sym), n, maxcycles, ol.ptr(ret), ol.ptr(cyc), ol.ptr(met), ol.ptr(mnp), ol.ptr(dat)) == 0
-        dt = time.time() - t0
-        nto = 0
-        for i in range(n):
-            s = (C.c_ubyte * 162)(*sym[i].tolist())
-            L.deinterleave(s)
-            dec = (C.c_ubyte * 11)(); a = C.c_uint(); b = C.c_uint(); c = C.c_uint()
-            r = L.fano(C.byref(a), C.byref(b), C.byref(c), dec, s, C.c_uint(81), mt, C.c_int(60), C.c_uint(maxcycles))
-            assert (ret[i], cyc[i], met[i], mnp[i]) == (r, b.value, a.value, c.value), (i, maxcycles)
-            if r == 0:
-                assert list(dat[i]) == list(dec)[:10]
-            nto += r != 0
-        print("device fano: maxcycles %d, %d vectors, %d time-outs, %.1f ms" % (maxcycles, n, nto, dt * 1e3))
-        assert 20 < nto < n - 20
-
-
 def test_wave_fano_equals_host_fano(w):
     """K6w (fano_wave.h): one wavefront per vector, 64 tree visits per step.  Return code, cycle count
     and decoded bytes equal the host routine's (= the reference's fano.c) for decodable vectors, early
