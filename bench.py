@@ -284,6 +284,8 @@ def main():
                          "per decoder call, default 1024, fed by front-end waves of --raw-segments)")
     ap.add_argument("--raw-segments", type=int, default=64,
                     help="--config 5: distinct raw segments resident in HBM (576 MB each) = one front-end wave")
+    ap.add_argument("--k0-cus", type=int, default=None,
+                    help="--config 5: CUs the front end may occupy (wspr_set_front_end_cus; 0 = all)")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
@@ -293,7 +295,7 @@ def main():
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight (default: 4 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
+                    help="batches in flight (default: 6 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
     ap.add_argument("--spawn", action="store_true",
                     help="take the launcher path even for --gpus 1 (one rank under torch.distributed.run with the RCCL "
@@ -320,17 +322,20 @@ def main():
     assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
+    if args.k0_cus is not None:
+        L.wspr_set_front_end_cus(args.k0_cus)
 
     opt = w.default_options()
     if use_dist:
         opt = wd.broadcast_options(opt, src=0)          # fan-out of the (tiny) job description
     cpus_here = int(os.environ["WSPR_HOST_THREADS"])
     # crowded band (configs[2]): the Fano attempts run on the device (library default for such batches), the host
-    # only keeps books, and four batches in flight cover the device round trips of a wave (25.5 / 25.9 / 27.2 k
-    # segments/s with 2 / 3 / 4 in flight; also with 2 host threads); otherwise two if the rank has the CPUs
-    inflight = args.inflight if args.inflight else (4 if args.config == 3 else
+    # only keeps books, and several batches in flight cover the device round trips of a wave (round 2: 25.5 / 25.9 /
+    # 27.2 k segments/s with 2 / 3 / 4 in flight; round 3: 30.7 / 31.8 / 30.9 k with 4 / 6 / 8); otherwise two if the
+    # rank has the CPUs
+    inflight = args.inflight if args.inflight else (6 if args.config == 3 else
                                                    (3 if args.config == 2 and cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
-    inflight = max(1, min(inflight, 4))
+    inflight = max(1, min(inflight, 8))
     from concurrent.futures import ThreadPoolExecutor
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
 
@@ -545,11 +550,27 @@ def main():
             t0 = time.perf_counter()
             L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
             roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
-            L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
-            t0 = time.perf_counter()
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
-            roof["measured_copy16_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9     # 16 bytes per lane
+            # the tuned copy (16 bytes per lane, four loads in flight per lane, resident grid), by cache policy: HIP events
+            L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+            cms = C.c_double(0.0)
+            tuned = {}
+            for variant, name in ((0, "nontemporal_loads_and_stores"), (1, "nontemporal_stores"), (2, "default_policy")):
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, variant, None)
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, variant,
+                                    C.addressof(cms))
+                tuned[name] = 8.0 * n_copy / (cms.value * 1e-3) / 1e9
+            roof["measured_copy16_GBs"] = max(tuned.values())            # the ceiling of mixed read + write traffic here
+            roof["measured_copy16_by_policy_GBs"] = tuned
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 3, None)
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 3, C.addressof(cms))
+            roof["measured_write_only_GBs"] = 4.0 * n_copy / (cms.value * 1e-3) / 1e9
+            # ... and write-only in the spectrogram's pattern (64-byte pieces of 311 rows per group of 16 time blocks)
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 4, None)
+            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 4, C.addressof(cms))
+            roof["measured_write_only_spectrogram_pattern_GBs"] = (n_copy // (417 * 352)) * 311 * 22 * 64 / (cms.value * 1e-3) / 1e9
+            rd = (C.c_double * 1)()                                       # read-only: K0's access pattern over the same bytes
+            L.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
+            roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
             del src, dst
         cpu = None
         if args.config == 5:

@@ -293,9 +293,9 @@ int wspr_fano_batch_device_wave(const unsigned char *symbols, int n, unsigned ma
  * involved. */
 int wspr_device_count(void);
 int wspr_set_device(int device);
-/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to four
+/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to eight
  * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
- * this (returns the lane actually bound, 0..3; a fifth lane is reserved for receiver sessions); calls made from
+ * this (returns the lane actually bound, 0..7; a ninth lane is reserved for receiver sessions); calls made from
  * threads bound to different lanes may overlap, e.g. to start the next batch under the tail of the current one. */
 int wspr_bind_thread_lane(int lane);
 /* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
@@ -312,6 +312,11 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
  * host threads or the pipeline's previous batch met more than one time-out per ten segments (a crowded band),
  * the host otherwise (single calls always).  Results are identical in every mode.  Returns the previous value. */
 int wspr_set_fano_device_mode(int mode);
+/* CUs the whole-segment front end (K0) may occupy: 0 = all (default; env WSPR_K0_CUS), else its kernels run on a
+ * stream restricted to that many CUs (hipExtStreamCreateWithCUMask, spread over the XCDs), so that a decoder running
+ * on another lane keeps the rest of the chip: K0 is HBM-bound and needs bandwidth, not every CU.  Returns the
+ * previous value.  Results never depend on it. */
+int wspr_set_front_end_cus(int ncus);
 /* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
  * ms[0] = average milliseconds per launch. */
 int wspr_bench_decimate(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_idat, void *d_qdat,
@@ -323,8 +328,10 @@ int wspr_calib_read(const void *d_raw, size_t bytes_per_seg, int nseg, int iters
 /* PMC calibration: `iters` launches of a 4-byte-per-lane stream copy of nfloats floats on the
  * library's stream (known traffic: 4*nfloats bytes read and written per launch). */
 int wspr_calib_copy(const void *d_src, void *d_dst, size_t nfloats, int iters);
-/* The same copy with 16 bytes per lane (nfloats a multiple of 4, 16-byte aligned buffers). */
-int wspr_calib_copy16(const void *d_src, void *d_dst, size_t nfloats, int iters);
+/* The tuned copy: 16 bytes per lane, four loads in flight per lane, resident grid (nfloats a multiple of 4, 16-byte
+ * aligned buffers).  variant: 0 = non-temporal loads and stores, 1 = default loads + non-temporal stores, 2 = default
+ * both, 3 = write only (d_dst is filled with 1.0f, d_src is not read).  ms (may be NULL) = average milliseconds per launch, HIP events on the launch stream. */
+int wspr_calib_copy16(const void *d_src, void *d_dst, size_t nfloats, int iters, int variant, double *ms);
 /* Vector-pipe calibration for the VALU rooflines: `launches` launches of register-only chains of separately
  * rounded packed multiplies and adds (v_pk_mul_f32 + v_pk_add_f32, no FMA) that fill every SIMD; *tflops =
  * sustained TFLOP/s (one flop per multiply or add), i.e. the practical ceiling of the decoder's arithmetic at the

@@ -381,12 +381,22 @@ int wspr_calib_copy(const void* d_src, void* d_dst, size_t nfloats, int iters) {
     } catch (const std::exception& e) { return fail("wspr_calib_copy", e); }
 }
 
-int wspr_calib_copy16(const void* d_src, void* d_dst, size_t nfloats, int iters) {
+int wspr_calib_copy16(const void* d_src, void* d_dst, size_t nfloats, int iters, int variant, double* ms) {
     try {
         if ((nfloats & 3) || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) return -1;
         Context& c = Context::get();
-        for (int i = 0; i < iters; ++i) wspr::launch_calib_copy16((const float*)d_src, (float*)d_dst, nfloats, c.stream());
-        c.sync();
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c.stream()));
+        for (int i = 0; i < iters; ++i) wspr::launch_calib_copy16((const float*)d_src, (float*)d_dst, nfloats, c.stream(), variant);
+        HIP_TRY(hipEventRecord(e1, c.stream()));
+        HIP_TRY(hipEventSynchronize(e1));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (ms) *ms = iters > 0 ? t / iters : 0.0;
         return 0;
     } catch (const std::exception& e) { return fail("wspr_calib_copy16", e); }
 }
@@ -435,6 +445,10 @@ int wspr_bind_thread_lane(int lane) {
 
 unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
     return wspr::fano_fast_budget().exchange(cycles_per_bit);
+}
+
+int wspr_set_front_end_cus(int ncus) {
+    return wspr::front_end_cus().exchange(ncus < 0 ? 0 : ncus);
 }
 
 int wspr_set_fano_device_mode(int mode) {

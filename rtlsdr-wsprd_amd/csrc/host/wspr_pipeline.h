@@ -21,6 +21,8 @@ std::atomic<unsigned>& fano_fast_budget();
 std::atomic<int>& fano_device_setting();
 // shards of a node-level call sharing this host's CPUs (see wspr_decode_batch_node)
 std::atomic<int>& node_share();
+// CUs the front end (K0) may occupy, 0 = all (wspr_set_front_end_cus / WSPR_K0_CUS)
+std::atomic<int>& front_end_cus();
 
 struct PendingFano {
     std::vector<int> seg;                 // owning segment of each attempt
@@ -50,7 +52,7 @@ public:
     static Context& get();          // slot 0; throws std::runtime_error when no HIP device is usable
     static Context& slot(int i);    // i in [0, slots())
     static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
-    static constexpr int kMaxLanes = 5;          // lanes 0..3 for callers, the last one for receiver sessions (feed)
+    static constexpr int kMaxLanes = 9;          // lanes 0..7 for callers, the last one for receiver sessions (feed)
     static constexpr int kUserLanes = kMaxLanes - 1;
     static constexpr int kMaxDevices = 16;
     static int lane();              // lane of the calling thread
@@ -61,6 +63,7 @@ public:
     ~Context();
 
     hipStream_t stream();
+    hipStream_t front_end_stream();   // the CU-masked stream of K0 when a share is set, else stream()
     const DeviceTables& tables();
     int host_threads();
 

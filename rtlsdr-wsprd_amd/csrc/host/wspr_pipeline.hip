@@ -151,6 +151,8 @@ private:
 // ---------------------------------------------------------------- context ----
 struct Context::Impl {
     hipStream_t stream = nullptr;
+    hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
+    int fe_cus = 0;                    // CUs the mask of fe_stream admits (0: fe_stream not in use)
     int device = 0;
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
@@ -1430,6 +1432,7 @@ int Context::bench_valu(int nseg, int samples, int iters, double* ms) {
 int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int iters,
                             double* ms) {
     Impl& c = *d;
+    const hipStream_t st = front_end_stream();          // the stream (and CU share) decimate_device() uses
     const size_t nblocks = bytes_per_seg / 2 / 6401;
     if (nblocks == 0) return -1;
     int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
@@ -1437,16 +1440,16 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0));
     HIP_OK(hipEventCreate(&e1));
-    HIP_OK(hipEventRecord(e0, c.stream));
+    HIP_OK(hipEventRecord(e0, st));
     for (int it = 0; it < iters; ++it) {
         if (!dI) {                                            // read calibration: K0's access pattern, no arithmetic
-            launch_calib_read(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, reinterpret_cast<unsigned*>(d_nv), c.stream);
+            launch_calib_read(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, reinterpret_cast<unsigned*>(d_nv), st);
             continue;
         }
-        launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream);
-        launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
+        launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, st);
+        launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, st);
     }
-    HIP_OK(hipEventRecord(e1, c.stream));
+    HIP_OK(hipEventRecord(e1, st));
     HIP_OK(hipEventSynchronize(e1));
     float t = 0;
     HIP_OK(hipEventElapsedTime(&t, e0, e1));
@@ -1614,21 +1617,51 @@ void Context::subtract_symbolwise_single(float* id, float* qd, long np, float f0
     store_host(id, qd, 1, samples, (size_t)samples);
 }
 
+// CUs the front end may occupy (0 = all).  K0 is HBM-bound and launches hundreds of thousands of short workgroups:
+// on an unmasked stream they take every CU as it frees up and the decoder's fp32-bound kernels of the other lanes
+// wait.  Confined to a share of the CUs (a stream created with hipExtStreamCreateWithCUMask; consecutive mask bits
+// fall on different XCDs, so the share is spread over all eight and keeps every HBM stack busy), K0 still finds
+// the memory bandwidth it needs while the rest of the chip keeps computing.
+std::atomic<int>& front_end_cus() {
+    static std::atomic<int> v{[] { const char* e = getenv("WSPR_K0_CUS"); return e ? atoi(e) : 0; }()};
+    return v;
+}
+
+hipStream_t Context::front_end_stream() {
+    Impl& c = *d;
+    const int want = front_end_cus().load();
+    if (want != c.fe_cus) {
+        if (c.fe_stream) { (void)hipStreamSynchronize(c.fe_stream); (void)hipStreamDestroy(c.fe_stream); c.fe_stream = nullptr; }
+        c.fe_cus = want;
+        if (want > 0) {
+            hipDeviceProp_t prop;
+            HIP_OK(hipGetDeviceProperties(&prop, c.device));
+            const int ncu = prop.multiProcessorCount;
+            const int n = std::max(8, std::min(want, ncu));
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
+            HIP_OK(hipExtStreamCreateWithCUMask(&c.fe_stream, (uint32_t)mask.size(), mask.data()));
+        }
+    }
+    return c.fe_stream ? c.fe_stream : c.stream;
+}
+
 int Context::decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
                              int* h_nout, DecimState* d_states) {
     Impl& c = *d;
+    const hipStream_t st = d_states ? c.stream : front_end_stream();     // whole segments only: streaming chunks are small
     const size_t nblocks = (size_t)decimate_blocks(bytes_per_seg / 2, d_states != nullptr);
     if (nblocks == 0) return -1;
     int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
     int* d_nv = static_cast<int*>(c.nvalid.need((size_t)nseg * 4));
     if (!d_states) {                                          // whole segments: the unfilled tail must read as zero
-        HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, c.stream));
-        HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, c.stream));
+        HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, st));
+        HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, st));
     }
-    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, c.stream, d_states);
-    if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, c.stream);
-    if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipStreamSynchronize(c.stream));
+    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, st, d_states);
+    if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, st);
+    if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     return 0;
 }
 

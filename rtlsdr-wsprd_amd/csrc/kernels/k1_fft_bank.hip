@@ -384,16 +384,70 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const float* __restrict
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, st, src, dst, n);
 }
-// the same copy with 16 bytes per lane (n a multiple of 4, 16-byte aligned buffers): the ceiling a kernel that
-// moves whole 16-byte words could reach
+// Tuned stream copy, the ceiling of mixed read + write traffic: 16 bytes per lane, kCopyInFlight independent loads
+// per lane issued before the first store, non-temporal in both directions (nothing is reused), a grid-stride loop
+// over a resident grid (8 workgroups of 256 per CU: every wave slot filled once, no tail).  variant selects the
+// cache policy so that the best one can be found on the box at hand: 0 = non-temporal loads and stores,
+// 1 = default loads + non-temporal stores, 2 = default both (round 2's kernel, but with loads in flight).
 namespace {
-__global__ __launch_bounds__(256) void calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+constexpr int kCopyInFlight = 4;
+typedef float f4c __attribute__((ext_vector_type(4)));
+template <int kVariant>
+__global__ __launch_bounds__(256) void calib_copy16_kernel(const f4c* __restrict__ src, f4c* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (kCopyInFlight - 1) * stride < n4; i += kCopyInFlight * stride) {
+        f4c v[kCopyInFlight];
+#pragma unroll
+        for (int u = 0; u < kCopyInFlight; ++u)
+            v[u] = kVariant == 0 ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < kCopyInFlight; ++u) {
+            if (kVariant <= 1) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 }  // namespace
-void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(calib_copy16_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), n / 4);
+// write-only stream (non-temporal 16-byte stores of a constant): what the memory system takes in one direction
+namespace {
+__global__ __launch_bounds__(256) void calib_fill16_kernel(f4c* __restrict__ dst, size_t n4, float value) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const f4c v = {value, value, value, value};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) __builtin_nontemporal_store(v, dst + i);
+}
+}  // namespace
+// write-only stream in the SPECTROGRAM's pattern: one workgroup per segment walks the 22 groups of 16 time blocks and
+// stores, per group, a 64-byte piece of each of the 311 bin rows the fused K1 sends to HBM (rows 1408 bytes apart) --
+// K1's stores without its arithmetic
+namespace {
+__global__ __launch_bounds__(256) void calib_fill_ps_kernel(float* __restrict__ ps, float value) {
+    float* __restrict__ out = ps + (size_t)blockIdx.x * kPsBins * kPsTPitch;
+    const f4c v = {value, value, value, value};
+    for (int g = 0; g < 22; ++g)
+        for (int e = threadIdx.x + 52 * 4; e < 363 * 4; e += 256) {
+            const int b = e >> 2, part = e & 3;
+            __builtin_nontemporal_store(v, reinterpret_cast<f4c*>(out + (size_t)b * kPsTPitch + 16 * g + 4 * part));
+        }
+}
+}  // namespace
+void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st, int variant) {
+    if (variant == 4) {                                      // n floats of room: floor(n / (417 * 352)) segments
+        const int nseg = (int)(n / ((size_t)kPsBins * kPsTPitch));
+        if (nseg > 0) hipLaunchKernelGGL(calib_fill_ps_kernel, dim3(nseg), dim3(256), 0, st, dst, 1.0f);
+        return;
+    }
+    if (variant == 3) {
+        hipLaunchKernelGGL(calib_fill16_kernel, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<f4c*>(dst), n / 4, 1.0f);
+        return;
+    }
+    const f4c* s4 = reinterpret_cast<const f4c*>(src);
+    f4c* d4 = reinterpret_cast<f4c*>(dst);
+    const dim3 grid(256 * 8), block(256);
+    if (variant == 0) hipLaunchKernelGGL(calib_copy16_kernel<0>, grid, block, 0, st, s4, d4, n / 4);
+    else if (variant == 1) hipLaunchKernelGGL(calib_copy16_kernel<1>, grid, block, 0, st, s4, d4, n / 4);
+    else hipLaunchKernelGGL(calib_copy16_kernel<2>, grid, block, 0, st, s4, d4, n / 4);
 }
 
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,

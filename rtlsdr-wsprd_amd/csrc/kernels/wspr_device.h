@@ -84,7 +84,7 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
 void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                          int samples, float* ps, float* psavg, const DeviceTables& t, hipStream_t st);
 void launch_calib_copy(const float* src, float* dst, size_t n, hipStream_t st);
-void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st);
+void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st, int variant = 0);
 
 // Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device, once per device (a process that drives
 // several devices through wspr_set_device reaches every launch site from each of them).

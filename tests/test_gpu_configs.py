@@ -302,7 +302,7 @@ def test_receiver_session_rollover_during_a_feed(env):
     L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.wspr_session_samples.restype = C.POINTER(C.c_float)
     L.wspr_session_destroy.argtypes = [C.c_void_p]
-    assert L.wspr_bind_thread_lane(7) == 3 and L.wspr_bind_thread_lane(0) == 0      # lane 4 is the sessions'
+    assert L.wspr_bind_thread_lane(11) == 7 and L.wspr_bind_thread_lane(0) == 0      # lane 8 is the sessions'
     CB, NCB = 65536, 600
     rng = np.random.default_rng(99)
     host = rng.integers(0, 256, CB * NCB, dtype=np.uint8)
@@ -368,14 +368,26 @@ def test_calibration_hooks_report_plausible_ceilings(env):
     n = 1 << 26
     src = torch.empty(n, device=dev, dtype=torch.float32).normal_(); dst = torch.empty_like(src)
     w.sync_torch()
-    for fn in (L.wspr_calib_copy, L.wspr_calib_copy16):
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert fn(src.data_ptr(), dst.data_ptr(), n, 2) == 0
-        t0 = time.perf_counter()
-        assert fn(src.data_ptr(), dst.data_ptr(), n, 10) == 0
-        gbs = 10 * 8.0 * n / (time.perf_counter() - t0) / 1e9
-        assert 1500.0 < gbs < 8000.0, gbs
+    L.wspr_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert L.wspr_calib_copy(src.data_ptr(), dst.data_ptr(), n, 2) == 0
+    t0 = time.perf_counter()
+    assert L.wspr_calib_copy(src.data_ptr(), dst.data_ptr(), n, 10) == 0
+    gbs = 10 * 8.0 * n / (time.perf_counter() - t0) / 1e9
+    assert 1500.0 < gbs < 8000.0, gbs
+    assert torch.equal(src, dst)
+    L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    cms = C.c_double(0.0)
+    for variant in (0, 1, 2):                                  # the tuned copy under its three cache policies
+        dst.zero_()
+        w.sync_torch()
+        assert L.wspr_calib_copy16(src.data_ptr(), dst.data_ptr(), n, 5, variant, C.addressof(cms)) == 0
+        gbs = 8.0 * n / (cms.value * 1e-3) / 1e9
+        assert 2500.0 < gbs < 8000.0, (variant, gbs)
         assert torch.equal(src, dst)
+    odd = n - 4 * 37                                           # a length the unrolled loop does not divide
+    dst.zero_(); w.sync_torch()
+    assert L.wspr_calib_copy16(src.data_ptr(), dst.data_ptr(), odd, 1, 0, None) == 0
+    assert torch.equal(src[:odd], dst[:odd]) and not dst[odd:].any()
     raw = torch.randint(1, 256, (4, bench.RAW_BYTES), device=dev, dtype=torch.uint8)
     w.sync_torch()
     ms = (C.c_double * 1)()
