@@ -252,7 +252,7 @@ def launch_ranks(n):
     torch.distributed.run (one rank per GPU, RCCL over xGMI, rendezvous on 127.0.0.1), each rank with its share of
     the host's CPUs.  Fails loudly if the node has fewer than N GPUs."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not (os.environ.get("WSPR_BENCH_SHARE_GPU") == "1" and have >= 1):
         sys.exit("bench.py: --gpus %d but only %d HIP device(s) visible on this node" % (n, have))
     import socket
     with socket.socket() as sk:
@@ -312,13 +312,21 @@ def main():
     # host Fano pool: share the host's cores between the ranks of this node
     os.environ.setdefault("WSPR_HOST_THREADS", str(max(2, usable_cpus() // max(1, world))))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook for 1-GPU boxes (tests/test_gpu_configs.py): WSPR_BENCH_SHARE_GPU=1 lets the ranks share the devices
+    # there are, WSPR_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device)
+    if os.environ.get("WSPR_BENCH_SHARE_GPU") == "1":
+        local %= max(1, torch.cuda.device_count())
+    backend = os.environ.get("WSPR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("WSPR_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
@@ -436,7 +444,7 @@ def main():
             fence()
             el = time.perf_counter() - t0
             if use_dist:
-                tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+                tmax = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             return el, out
@@ -479,7 +487,7 @@ def main():
         def decode_rows(mi, mq, o):
             d = w.BatchDecoder(mi.shape[0], max_results=16, options=o)
             if mi.shape[0]:
-                d.decode(mi.contiguous(), mq.contiguous())
+                d.decode(mi.to(dev).contiguous(), mq.to(dev).contiguous())
             return d.out, d.nres
         res = wd.decode_from_root(m["I"][:ntot, :NS] if rank == 0 else None, m["Q"][:ntot, :NS] if rank == 0 else None,
                                   ntot, NS, opt, decode_rows, max_results=16, record_size=rec, root=0)
@@ -489,7 +497,8 @@ def main():
                     for s in range(ntot)]
             same = sum(1 for s in range(ntot) if back[s] == sorted(m["got"][s]))
             fanout = {"segments_scattered_from_rank0": ntot, "bytes_per_segment": 2 * 4 * NS,
-                      "equal_to_rank0_own_decode": "%d/%d" % (same, ntot), "over": "rccl send/recv (grouped)"}
+                      "equal_to_rank0_own_decode": "%d/%d" % (same, ntot),
+                      "over": "rccl send/recv (grouped)" if backend == "nccl" else backend + " send/recv"}
 
     if rank == 0:
         I, Q = m["I"], m["Q"]
@@ -612,7 +621,7 @@ def main():
             "config": {"workload": m["workload"] + ", 45000 complex f32 samples @ 375 sps, resident in HBM; reference "
                                    "defaults (npasses 2, subtraction on, quickmode off)",
                        "segments_per_gpu": nseg, "parallelism": "segments sharded per GPU, spots gathered on rank 0",
-                       "gathered_over": "rccl" if use_dist else "none (one process)",
+                       "gathered_over": ("rccl" if backend == "nccl" else backend) if use_dist else "none (one process)",
                        "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("WSPR_BENCH_SPAWNED")
                        else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
                        "batches_in_flight": inflight, "untimed_steps": m["untimed"]},
