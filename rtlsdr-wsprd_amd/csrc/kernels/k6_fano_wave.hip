@@ -14,9 +14,12 @@
 //   cut     a completed frame drops everything later in walk order
 //   scan    output slots by ballot/mbcnt; ledger flow by one DPP prefix sum + one bpermute
 //   push    children written back in walk order (top of the stack = earliest)
-// Integer work, latency bound.  The stack lives either in a per-wave slice of device memory (default:
-// 4 096 visits, L2-resident, 1.3 KB of LDS per wave -> 32 waves per CU) or in LDS (1 024 visits, 21 KB
-// per wave -> 7 waves per CU; the step narrows when the store fills).
+// Integer work, latency bound.  The stack is a per-wave slice of device memory (4 096 visits) whose TOP lives in LDS:
+// a step pops at most 64 visits and pushes at most 192, all within a few hundred entries of the top, so a circular
+// window of 512 entries (10 KB of LDS per wave, index & 511) serves every access of a step at LDS latency; when the
+// top moves out of the window, half a window (256 entries, 5 KB) is spilled to / filled from the wave's slice in one
+// coalesced burst.  (Round 2 kept the whole stack in device memory: two dependent memory round trips per step,
+// ~1.3 us, 10 ms for a full time-out; or 1 024 visits in LDS: 21 KB per wave, 7 waves per CU.)
 #include "wspr_device.h"
 #include "fano_wave.h"
 #include <cstdlib>
@@ -47,21 +50,27 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // popco
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-// kGlobal: the pending-visit store lives in a per-wave slice of device memory (L2-resident: only the top of
-// the stack is touched) instead of LDS.  A step then costs two memory round trips instead of two LDS ones,
-// but a wave needs 1.3 KB of LDS instead of 21 KB, so 32 waves per CU hide that latency (7 with the LDS
-// store) and the kernel no longer starves co-running kernels of LDS.
-template <int kCap, bool kGlobal>
+constexpr int kWin = 512, kHalf = kWin / 2;                 // LDS window over the top of the stack; see the invariants below
+static_assert(kHalf >= 64 && kWin - 192 >= kHalf, "a step's pops (<= 64) and pushes (<= 192) must fit beside the half that moves");
+
+template <int kCap>
 __global__ __launch_bounds__(64)
 void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __restrict__ offsets, int n,
                       const short* __restrict__ metric0, unsigned maxcycles,
                       int* __restrict__ ret, unsigned* __restrict__ cycles, unsigned* __restrict__ metric,
                       unsigned* __restrict__ maxnp, unsigned char* __restrict__ data, unsigned* __restrict__ steps_out,
                       uint32_t* __restrict__ gpool, int* __restrict__ next_vector) {
-    __shared__ uint32_t lpool[kGlobal ? 1 : 5 * kCap];
-    uint32_t* __restrict__ gp = kGlobal ? gpool + (size_t)blockIdx.x * 5 * kCap : nullptr;
-    auto ld = [&](int arr, int i) -> uint32_t { if constexpr (kGlobal) return gp[arr * kCap + i]; else return lpool[arr * kCap + i]; };
-    auto st_ = [&](int arr, int i, uint32_t v) { if constexpr (kGlobal) gp[arr * kCap + i] = v; else lpool[arr * kCap + i] = v; };
+    // entry i of the stack is in LDS slot i & (kWin - 1) while lo <= i < lo + kWin (lo: wave-uniform, a multiple of
+    // kHalf); entries below lo are in the wave's slice of device memory gp[arr][i]
+    __shared__ uint32_t lpool[5 * kWin];
+    uint32_t* __restrict__ gp = gpool + (size_t)blockIdx.x * 5 * kCap;
+    auto ld = [&](int arr, int i) -> uint32_t { return lpool[arr * kWin + (i & (kWin - 1))]; };
+    auto st_ = [&](int arr, int i, uint32_t v) { lpool[arr * kWin + (i & (kWin - 1))] = v; };
+    auto lds_order = [] {        // one wave: its LDS operations complete in order; only the compiler must not move them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     __shared__ uint2 bm[kBits];
     __shared__ unsigned char symd[kNSymD];
     __shared__ short mt[256];
@@ -106,10 +115,10 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         st_(0, 0, 0u); st_(1, 0, 0u); st_(2, 0, pack_meta(0u, 0, true)); st_(3, 0, pack_gt(0, 0)); st_(4, 0, 0u);
     }
     __syncthreads();
-    if constexpr (kGlobal) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
     const unsigned budget = maxcycles * (unsigned)kBits;
     int size = 1;                    // wave-uniform
+    int lo = 0;                      // wave-uniform: first stack index held in LDS
     unsigned settled = 0;            // looks before the earliest pending visit: final
     unsigned steps = 0;
     int rc = -2;
@@ -126,6 +135,21 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         const int take = min(min(wide, size), room >> 1);
         if (take < 1 || steps > 4u * budget + 1024u) { rc = -2; break; }
         ++steps;
+        // the visits popped now are [size - take, size): slide the window down when they start below it.  The slots
+        // the fill overwrites held [lo + kHalf, lo + kWin), all dead: size - take < lo and take <= 64 give size < lo + kHalf.
+        if (size - take < lo) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // an earlier spill's stores (other lanes') have landed
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lo -= kHalf;
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr)
+#pragma unroll
+                for (int u = 0; u < kHalf / 64; ++u) {
+                    const int i = lo + 64 * u + lane;
+                    lpool[arr * kWin + (i & (kWin - 1))] = gp[arr * kCap + i];
+                }
+            lds_order();
+        }
         const bool active = lane < take;
         const int idx = size - 1 - (active ? lane : 0);
         Visit x{ld(0, idx), ld(1, idx), ld(2, idx), ld(3, idx), ld(4, idx)};
@@ -152,6 +176,7 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
             const int jc = __builtin_ctzll(stop_mask);
             live = active && lane <= jc;
             base = 0;
+            lo = 0;                                                  // the stack restarts at its bottom: so does the window
         }
         const bool keep_self = live && (is_done_visit || e.done);
         const bool has0 = live && !keep_self && e.has0;
@@ -173,6 +198,19 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
         const uint32_t gain = pre_nxt - pre;                                      // looks between my last output and the next one
         const int first = has_mask ? __builtin_ctzll(has_mask) : 63;
         settled += (uint32_t)__builtin_amdgcn_readlane((int)pre, first);
+        // the visits pushed now are [base, base + total), total <= 192: slide the window up when they end above it.  The
+        // half that is spilled, [lo, lo + kHalf), lies below base: base + total > lo + kWin gives base > lo + kWin - 192.
+        if (base + total > lo + kWin) {
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr)
+#pragma unroll
+                for (int u = 0; u < kHalf / 64; ++u) {
+                    const int i = lo + 64 * u + lane;
+                    gp[arr * kCap + i] = lpool[arr * kWin + (i & (kWin - 1))];
+                }
+            lo += kHalf;
+            lds_order();                                             // the slots are read before the pushes below overwrite them
+        }
         // push
         const int top = base + total - 1;
         const uint32_t tail_led = x.led + gain;
@@ -193,18 +231,7 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
             st_(4, w, keep_self ? 0u : tail_led);
         }
         size = base + total;
-        if constexpr (kGlobal) {
-            // the stores must have reached the cache the next step's loads read from (other lanes of this
-            // wave read them): workgroup-scope release/acquire = wait for the stores, nothing is flushed
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        } else {
-            // one wave: its LDS operations complete in order, so the next step's reads see these writes; only
-            // the compiler has to be kept from moving them
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        lds_order();
     }
     if (lane == 0) {
         ret[v] = rc;
@@ -222,28 +249,21 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
 
 }  // namespace
 
-constexpr int kWaveGrid = 8192;                              // 256 CUs x 32 waves
+// resident grid: 13 single-wave workgroups per CU by LDS (11.5 KB each); a persistent loop takes the vectors
+constexpr int kWaveGrid = 256 * 13;
 
-size_t fano_wave_scratch_words(int n) {                     // device scratch for the global-store form
-    return (size_t)std::min(n, kWaveGrid) * 5 * 4096 + 16;   // + the work counter
+size_t fano_wave_scratch_words(int n) {                     // the waves' stack slices + the work counter
+    return (size_t)std::min(n, kWaveGrid) * 5 * 4096 + 16;
 }
 
 void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, const short* metric0,
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
                       unsigned char* data, unsigned* steps, uint32_t* scratch, hipStream_t st) {
     if (n <= 0) return;
-    // WSPR_FANO_WAVE_STORE=lds: the 1024-visit store in LDS (7 waves per CU, one workgroup per vector); default:
-    // 4096 visits per wave in device memory (scratch = fano_wave_scratch_words(n) words) and a persistent grid
-    static const bool lds = [] { const char* e = getenv("WSPR_FANO_WAVE_STORE"); return e && e[0] == 'l'; }();
-    if (lds || !scratch) {
-        hipLaunchKernelGGL((fano_wave_kernel<1024, false>), dim3(n), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
-                           ret, cycles, metric, maxnp, data, steps, (uint32_t*)nullptr, (int*)nullptr);
-        return;
-    }
     const int grid = std::min(n, kWaveGrid);
     int* counter = reinterpret_cast<int*>(scratch + (size_t)grid * 5 * 4096);
     (void)hipMemsetAsync(counter, 0, sizeof(int), st);
-    hipLaunchKernelGGL((fano_wave_kernel<4096, true>), dim3(grid), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
+    hipLaunchKernelGGL((fano_wave_kernel<4096>), dim3(grid), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
                        ret, cycles, metric, maxnp, data, steps, scratch, counter);
 }
 

@@ -149,8 +149,7 @@ void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int
 // One wavefront per vector, 64 tree visits per step (k6_fano_wave.hip): exact return
 // code, cycle count and decoded bytes; metric/maxnp only for decoded frames.  ret -2 = the wave's
 // pending-visit store overflowed (the caller decodes that vector some other way).  steps may be null.
-// scratch: fano_wave_scratch_words(n) words of device memory (the waves' pending-visit stores), or null for the
-// LDS-store form.
+// scratch: fano_wave_scratch_words(n) words of device memory (the waves' stack slices; their tops live in LDS).
 size_t fano_wave_scratch_words(int n);
 void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, const short* metric0,
                       unsigned maxcycles, int* ret, unsigned* cycles, unsigned* metric, unsigned* maxnp,
