@@ -507,7 +507,7 @@ def main():
         L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 5, C.addressof(ms))
         k1, k2, k3 = ms[0], ms[1], ms[2]
         traffic, traffic_src = None, None
-        for name in ("r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json"):
+        for name in ("r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json"):
             tf = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tf):
                 jd = json.load(open(tf))
