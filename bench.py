@@ -153,7 +153,9 @@ def usable_cpus():
 
 
 K4_FLOP = 33 * 162 * 256 * 32                 # mode-0 lag scan per candidate: 43.8 MFLOP
-K41_FLOP = 5 * 162 * 256 * 32                 # mode-1 frequency scan per candidate: 6.6 MFLOP
+K41_FLOP = 4 * 162 * 256 * 32                 # mode-1 frequency scan per candidate: the reference sums five hypotheses
+                                              # (6.6 MFLOP); the kernel sums FOUR (5.3 MFLOP) and copies the centre one from
+                                              # the lag scan, so only four are credited
 K7_FLOP = 64.3e6                              # subtract_signal2 per decoded signal
 VALU_PEAK_TF = 157.3                          # fp32 vector peak (FMA counted as 2), MI355X_MICROARCH.md
 VALU_NOFMA_TF = 78.6                          # the same pipes issuing separately rounded mul / add
@@ -547,7 +549,7 @@ def main():
                                     "half the FMA peak",
                             "K4_lag_scan (demod_lag3_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
                             "K4_freq_scan_first_rung (freq_scalar_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
-                            "K7_subtract (sub_runs + sub_ref + sub_filter8 kernels)": valu(K7_FLOP, vms[3], vms[1])}
+                            "K7_subtract (sub_runs_wave_kernel + sub_fir_fused_kernel)": valu(K7_FLOP, vms[3], vms[1])}
         # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
         # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
         if args.config != 5:

@@ -5,16 +5,16 @@
 //   c(t) = LPF[s(t) * conj(r(t))]   360-tap normalised sine window,
 //   s'(t) = s(t) - c(t) r(t) / edge_norm.
 //
-// Three kernels, each keeping the reference's evaluation order where it matters:
-//   sub_runs_kernel    phi is the reference's *float* running sum (41 472 serial adds, dphi
-//                      changes every 256 samples).  It is not walked: phase_runs.h decomposes
-//                      it exactly into ~200 linear runs per signal (one lane per job).
-//   sub_ref_kernel     fully parallel: every sample's phase from its run, glibc-exact sincos
-//                      (one shared argument reduction), r and the products s*conj(r).
-//   sub_filter_kernel  each low-pass output is one serial 360-term sum in tap order; a lane
-//                      owns 4 consecutive outputs and slides a 4-sample register window, the
-//                      tile is stored transposed-by-4 in LDS so the per-step read is
-//                      conflict-free; the epilogue subtracts c*r/norm in place.
+// Two kernels, each keeping the reference's evaluation order where it matters:
+//   sub_runs_wave_kernel   phi is the reference's *float* running sum (41 472 serial adds, dphi changes every
+//                          256 samples).  It is not walked: phase_runs.h decomposes it exactly into ~200 linear
+//                          runs per signal (one wave per job, up to 64 symbols probed at once).
+//   sub_fir_fused_kernel   per workgroup of 2 048 outputs: every input sample's phase from its run, glibc-exact
+//                          sincos (one shared argument reduction), r and the products s*conj(r) straight into the
+//                          LDS tile; each low-pass output is one serial 360-term sum in tap order, a lane owns 8
+//                          consecutive outputs and slides an 8-sample register window (tile transposed by 8: the
+//                          per-tap read is conflict-free), taps through the scalar cache; the epilogue subtracts
+//                          c*r/norm in place with r from LDS.
 // Bound: fp32 VALU (64 MFLOP of separately rounded mul/add per job), not HBM.
 #include "wspr_device.h"
 #include <cstdlib>
@@ -28,8 +28,7 @@ namespace {
 
 constexpr double kTwoPiDt = 2.0 * 3.14159265358979323846 * 1.0 / 375.0;
 
-// scratch (floats), per job: ref[kSigLen] float2 | cc[kSigLen] float2 | phase runs (PhaseTable)
-constexpr size_t kSubPerJob = 4 * (size_t)kSigLen;
+// scratch per job: the phase runs (PhaseTable)
 struct PhaseTable {
     PhaseRun runs[kPhaseMaxRuns];
     float sym_phi[kNSymD];           // phase of the first sample of every symbol
@@ -131,56 +130,6 @@ void sub_runs_wave_kernel(const SubJob* __restrict__ jobs, int njobs, PhaseTable
     }
 }
 
-// One workgroup walks kSymPerWg symbols (256 samples each) of one job.  All lanes of a wave sit in the
-// same symbol, so the symbol's few runs are fetched with wave-uniform (scalar) loads and every lane
-// keeps the last one that starts at or before its sample.
-constexpr int kSymPerWg = 6;
-static_assert(kNSymD % kSymPerWg == 0, "symbols per workgroup must divide 162");
-__global__ __launch_bounds__(256)
-void sub_ref_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                    const SubJob* __restrict__ jobs, const PhaseTable* __restrict__ tables,
-                    float* __restrict__ perjob) {
-    const int jobi = blockIdx.y, j = threadIdx.x;
-    const SubJob* job = jobs + jobi;
-    const PhaseTable& tb = tables[jobi];
-    const bool dense = tb.first_run[0] == 0xffffu;
-    const int shift = job->shift;
-    const float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
-    const float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
-    float2* __restrict__ ref = reinterpret_cast<float2*>(perjob + (size_t)jobi * kSubPerJob);
-    float2* __restrict__ cc = ref + kSigLen;
-#pragma unroll 1
-    for (int u = 0; u < kSymPerWg; ++u) {
-        const int sym = blockIdx.x * kSymPerWg + u;
-        const int n = sym * kSps + j;
-        float phi;
-        if (!dense) {
-            const int r0 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym]);
-            const int r1 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym + 1]);
-            PhaseRun pick = tb.runs[r0];
-            for (int r = r0 + 1; r < r1; ++r) {
-                const PhaseRun c = tb.runs[r];
-                if (c.start <= n) pick = c;
-            }
-            phi = phase_of(pick, n - pick.start);
-        } else {
-            phi = phase_from_symbol(tb.sym_phi[sym], tb.dphi[sym], j);
-        }
-        float sr, cr;
-        glibc_sincosf_pair(phi, &sr, &cr);
-        ref[n] = make_float2(cr, sr);
-        const int k = shift + n;
-        float a = 0.0f, b = 0.0f;
-        if (k > 0 && k < np) {
-            const float x = xi[k], y = xq[k];
-            const float p1 = x * cr, p2 = y * sr, p3 = y * cr, p4 = x * sr;
-            a = p1 + p2;                  // Re{s conj(r)}
-            b = p3 - p4;                  // Im{s conj(r)}
-        }
-        cc[n] = make_float2(a, b);
-    }
-}
-
 constexpr int kFirThreads = 256;
 // Eight outputs per lane, taps from scalar registers.  (With four outputs per lane and the taps in LDS a wave
 // issued 32 packed multiply/adds per four taps against one 16-byte and four 8-byte LDS reads, and with four SIMDs
@@ -195,32 +144,83 @@ constexpr int kFir8Span = kFir8Out + kLpfTaps - 1;                // 2407 inputs
 constexpr int kFir8Pitch = (kFir8Span + 7) / 8 + 1;               // transposed-by-8 row pitch (8-byte words)
 static_assert(kLpfTaps % 8 == 0, "taps are consumed eight at a time");
 
+// Reference r(t), the products s(t) conj(r(t)) and the FIR in ONE kernel (round 3): neither r nor s conj(r) travels
+// through HBM.  Rounds 1-2 had a kernel write both for the whole signal (16 bytes per sample) and the FIR read them
+// back: 2 GB per 2 048 jobs at the mixed-traffic ceiling of the memory system (0.545 ms of the set's 3.13 ms).  Here
+// the workgroup that filters outputs n0 .. n0 + 2047 forms s conj(r) for the 2 407 inputs it needs while it stages
+// them -- per sample: phase from the run table (every sample's phase from its run, phase_runs.h), glibc-exact sincos,
+// four products, two adds, exactly the operations of the former kernel -- and keeps r of its own 2 048 outputs in LDS
+// for the epilogue.  Inputs at the tile's edges are formed by two workgroups (2 407 / 2 048: 17.5 % more sincos
+// evaluations); set 3.13 -> 2.92 ms per 2 048 jobs, 664 KB of scratch per job gone.
+// Staging goes symbol by symbol (thread j = sample j of the symbol), so that a wave sits in ONE symbol and fetches
+// its few runs with wave-uniform (scalar) loads.
 __global__ __launch_bounds__(kFirThreads)
-void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
-                        const SubJob* __restrict__ jobs, const float* __restrict__ perjob,
-                        const float* __restrict__ lpf, const float* __restrict__ lpf_part) {
+void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
+                          const SubJob* __restrict__ jobs, const PhaseTable* __restrict__ tables,
+                          const float* __restrict__ lpf, const float* __restrict__ lpf_part, int* __restrict__ staged) {
     __shared__ float2 tile[8 * kFir8Pitch];
+    __shared__ float2 rref[kFir8Out];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const SubJob* job = jobs + blockIdx.y;
-    const float2* __restrict__ ref = reinterpret_cast<const float2*>(perjob + (size_t)blockIdx.y * kSubPerJob);
-    const float2* __restrict__ cc = ref + kSigLen;
+    const PhaseTable& tb = tables[blockIdx.y];
+    const bool dense = tb.first_run[0] == 0xffffu;
+    const int shift = job->shift;
+    float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
+    float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
     const int n0 = blockIdx.x * kFir8Out;
+    const int n_lo = n0 - kLpfTaps / 2, n_hi = n_lo + kFir8Span;            // inputs [n_lo, n_hi)
     // the reference filters a zero-padded copy (360 leading zeros); outside the signal the products are zero
-    for (int e0 = tid; e0 < kFir8Span; e0 += 4 * kFirThreads) {
-        float2 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * kFirThreads, n = n0 - kLpfTaps / 2 + e;
-            v[u] = (e < kFir8Span && n >= 0 && n < kSigLen) ? cc[n] : make_float2(0.0f, 0.0f);
+    if (n_lo < 0 || n_hi > kSigLen)
+        for (int e = tid; e < kFir8Span; e += kFirThreads) {
+            const int n = n_lo + e;
+            if (n < 0 || n >= kSigLen) tile[(e & 7) * kFir8Pitch + (e >> 3)] = make_float2(0.0f, 0.0f);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * kFirThreads;
-            if (e < kFir8Span) tile[(e & 7) * kFir8Pitch + (e >> 3)] = v[u];
+    const int sym_lo = max(n_lo, 0) >> 8, sym_hi = (min(n_hi, kSigLen) - 1) >> 8;
+#pragma unroll 1
+    for (int sym = sym_lo; sym <= sym_hi; ++sym) {
+        const int n = sym * kSps + tid;
+        if (n < n_lo || n >= n_hi) continue;                               // whole waves at a time except at the two ends
+        float phi;
+        if (!dense) {
+            const int r0 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym]);
+            const int r1 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym + 1]);
+            PhaseRun pick = tb.runs[r0];
+            for (int r = r0 + 1; r < r1; ++r) {
+                const PhaseRun c = tb.runs[r];
+                if (c.start <= n) pick = c;
+            }
+            phi = phase_of(pick, n - pick.start);
+        } else {
+            phi = phase_from_symbol(tb.sym_phi[sym], tb.dphi[sym], tid);
         }
+        float sr, cr;
+        glibc_sincosf_pair(phi, &sr, &cr);
+        const int k = shift + n;
+        float a = 0.0f, b = 0.0f;
+        if (k > 0 && k < np) {
+            const float x = xi[k], y = xq[k];
+            const float p1 = x * cr, p2 = y * sr, p3 = y * cr, p4 = x * sr;
+            a = p1 + p2;                  // Re{s conj(r)}
+            b = p3 - p4;                  // Im{s conj(r)}
+        }
+        const int e = n - n_lo;
+        tile[(e & 7) * kFir8Pitch + (e >> 3)] = make_float2(a, b);
+        if (n >= n0 && n < n0 + kFir8Out) rref[n - n0] = make_float2(cr, sr);
     }
     __syncthreads();
+    // The subtraction is IN PLACE and this workgroup has just read 180 samples on either side of its own outputs --
+    // samples its two neighbours will overwrite, as it will overwrite theirs.  Nobody may write before both
+    // neighbours have read: every workgroup raises a flag once its inputs are in LDS (all its loads have returned:
+    // their values were stored to LDS before the barrier above) and checks its neighbours' flags before its epilogue.
+    // The 21 workgroups of a job are dispatched back to back and staging is the first tenth of a workgroup's life, so
+    // the check normally passes at once; it cannot deadlock: only the last resident workgroup in dispatch order can
+    // wait for one that is not resident yet, and every other one finishes and frees its slot.
+    int* __restrict__ flags = staged + (size_t)blockIdx.y * gridDim.x;
+    // Relaxed, agent scope: nothing is PUBLISHED here -- the flag orders this workgroup's completed loads before its
+    // neighbours' later stores, and the barrier above already waited for those loads.  (A release store at agent
+    // scope writes the XCD's L2 back, 43 000 times per launch: measured 2.7 -> 4.0 ms per 2 048 jobs.)
+    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // outputs n0 + 8 tid + r, r = 0..7; input of tap j for output r: e = 8 tid + r + j
     v2f acc[8], x[8];
@@ -237,9 +237,7 @@ void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
         g.wa = w4[jj / 4];
         g.wb = w4[jj / 4 + 1];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                        // e = 8 tid + 8 + jj + u: row u (jj is a multiple of 8)
-            g.in[u] = tile[u * kFir8Pitch + tid + 1 + (jj >> 3)];
-        }
+        for (int u = 0; u < 8; ++u) g.in[u] = tile[u * kFir8Pitch + tid + 1 + (jj >> 3)];
     };
     auto consume = [&](const Stage& g) {
         const float w[8] = {g.wa.x, g.wa.y, g.wa.z, g.wa.w, g.wb.x, g.wb.y, g.wb.z, g.wb.w};
@@ -248,10 +246,10 @@ void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
             const v2f wu = {w[u], w[u]};
             v2f p[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) p[r] = wu * x[(u + r) & 7];          // window slot (u + r) & 7 holds sample e = 8 tid + r + j + u
+            for (int r = 0; r < 8; ++r) p[r] = wu * x[(u + r) & 7];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = acc[r] + p[r];
-            x[u & 7] = (v2f){g.in[u].x, g.in[u].y};                           // the oldest sample leaves, e = 8 tid + 8 + j + u enters
+            x[u & 7] = (v2f){g.in[u].x, g.in[u].y};
         }
     };
     Stage A, B;
@@ -273,6 +271,12 @@ void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (tid < 2) {                                           // thread 0: left neighbour, thread 1: right neighbour
+        const int nb = (int)blockIdx.x + (tid == 0 ? -1 : 1);
+        if (nb >= 0 && nb < (int)gridDim.x)
+            while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = n0 + 8 * tid + r;
@@ -280,11 +284,9 @@ void sub_filter8_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
         float norm = 1.0f;                                   // wsprd.c:397-404
         if (n < kLpfTaps / 2)                    norm = lpf_part[kLpfTaps / 2 + n];
         else if (n > kSigLen - 1 - kLpfTaps / 2) norm = lpf_part[kLpfTaps / 2 + kSigLen - 1 - n];
-        const int k = job->shift + n;
+        const int k = shift + n;
         if (k > 0 && k < np) {
-            float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
-            float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
-            const float2 rr = ref[n];
+            const float2 rr = rref[8 * tid + r];
             const float si = acc[r].x, sq = acc[r].y;
             const float a = si * rr.x, b = sq * rr.y, c = si * rr.y, d = sq * rr.x;
             const float ri = a - b, rq = c + d;
@@ -372,18 +374,19 @@ void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int
     hipLaunchKernelGGL(sub_symbolwise_kernel, dim3(kNSymD), dim3(kSps), 0, st, dI, dQ, samples, f0, shift, drift, d_sym);
 }
 
-// scratch floats needed for njobs jobs (per job: r and s*conj(r), then the phase-run tables)
-size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kSubPerJob + kTableFloats); }
+// scratch floats needed for njobs jobs: the phase-run tables + one "inputs staged" flag per workgroup of the FIR
+constexpr int kFirWgs = (kSigLen + kFir8Out - 1) / kFir8Out;      // 21
+size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kTableFloats + kFirWgs); }
 
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
                      float* scratch, const DeviceTables& t, hipStream_t st) {
     if (njobs <= 0) return;
-    float* perjob = scratch;
-    PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch + (size_t)njobs * kSubPerJob);
+    PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch);
+    int* staged = reinterpret_cast<int*>(scratch + (size_t)njobs * kTableFloats);
+    (void)hipMemsetAsync(staged, 0, (size_t)njobs * kFirWgs * sizeof(int), st);
     hipLaunchKernelGGL(sub_runs_wave_kernel, dim3(njobs), dim3(64), 0, st, jobs, njobs, tables);
-    hipLaunchKernelGGL(sub_ref_kernel, dim3(kNSymD / kSymPerWg, njobs), dim3(256), 0, st, dI, dQ, samples, jobs, tables, perjob);
-    hipLaunchKernelGGL(sub_filter8_kernel, dim3((kSigLen + kFir8Out - 1) / kFir8Out, njobs), dim3(kFirThreads), 0, st,
-                       dI, dQ, samples, jobs, perjob, t.lpf, t.lpf_part);
+    hipLaunchKernelGGL(sub_fir_fused_kernel, dim3(kFirWgs, njobs), dim3(kFirThreads), 0, st,
+                       dI, dQ, samples, jobs, tables, t.lpf, t.lpf_part, staged);
 }
 
 // Working copy of resident input: rows of `samples` floats (16-byte aligned, stride a multiple of 4) into
