@@ -143,6 +143,8 @@ constexpr int kFir8Out = kFirThreads * kFir8PerLane;              // 2048 output
 constexpr int kFir8Span = kFir8Out + kLpfTaps - 1;                // 2407 inputs
 constexpr int kFir8Pitch = (kFir8Span + 7) / 8 + 1;               // transposed-by-8 row pitch (8-byte words)
 static_assert(kLpfTaps % 8 == 0, "taps are consumed eight at a time");
+constexpr int kFirWgs = (kSigLen + kFir8Out - 1) / kFir8Out;      // 21 tiles per signal
+constexpr int kHalo = kLpfTaps / 2;                               // 180 samples of a neighbour's range on either side
 
 // Reference r(t), the products s(t) conj(r(t)) and the FIR in ONE kernel (round 3): neither r nor s conj(r) travels
 // through HBM.  Rounds 1-2 had a kernel write both for the whole signal (16 bytes per sample) and the FIR read them
@@ -150,14 +152,14 @@ static_assert(kLpfTaps % 8 == 0, "taps are consumed eight at a time");
 // the workgroup that filters outputs n0 .. n0 + 2047 forms s conj(r) for the 2 407 inputs it needs while it stages
 // them -- per sample: phase from the run table (every sample's phase from its run, phase_runs.h), glibc-exact sincos,
 // four products, two adds, exactly the operations of the former kernel -- and keeps r of its own 2 048 outputs in LDS
-// for the epilogue.  Inputs at the tile's edges are formed by two workgroups (2 407 / 2 048: 17.5 % more sincos
-// evaluations); set 3.13 -> 2.92 ms per 2 048 jobs, 664 KB of scratch per job gone.
+// for the epilogue.  Set 3.13 -> 2.89 ms per 2 048 jobs, 664 KB of scratch per job gone.
 // Staging goes symbol by symbol (thread j = sample j of the symbol), so that a wave sits in ONE symbol and fetches
 // its few runs with wave-uniform (scalar) loads.
 __global__ __launch_bounds__(kFirThreads)
 void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np,
                           const SubJob* __restrict__ jobs, const PhaseTable* __restrict__ tables,
-                          const float* __restrict__ lpf, const float* __restrict__ lpf_part, int* __restrict__ staged) {
+                          const float* __restrict__ lpf, const float* __restrict__ lpf_part, float2* __restrict__ halo,
+                          int parity) {
     __shared__ float2 tile[8 * kFir8Pitch];
     __shared__ float2 rref[kFir8Out];
     typedef float v2f __attribute__((ext_vector_type(2)));
@@ -168,7 +170,17 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
     const int shift = job->shift;
     float* __restrict__ xi = dI + (size_t)job->seg * kIqStride;
     float* __restrict__ xq = dQ + (size_t)job->seg * kIqStride;
-    const int n0 = blockIdx.x * kFir8Out;
+    // The subtraction is IN PLACE and a tile reads 180 samples on either side of its own outputs -- samples its two
+    // neighbours overwrite, as it overwrites theirs.  The tiles therefore run in two launches: the EVEN tiles first
+    // (their halos lie in odd tiles' ranges, which nobody writes in that launch), and while they stage they save
+    // s conj(r) of the first and last 180 samples of their own range (2.9 KB per tile); the ODD tiles second: their
+    // own range is still untouched, and the halos -- by now overwritten -- come from what the even tiles saved
+    // (the same values bit for bit: the same operations on the same samples).  No workgroup ever waits for another
+    // (round 3's first form had neighbours exchange flags: correct, and as fast alone, but its forward progress hung
+    // on the dispatcher -- with the front end on a CU-masked stream beside it a step took 8.9 s).
+    const int tile_idx = 2 * (int)blockIdx.x + parity;
+    float2* __restrict__ my_halo = halo + ((size_t)blockIdx.y * kFirWgs + tile_idx) * 2 * kHalo;
+    const int n0 = tile_idx * kFir8Out;
     const int n_lo = n0 - kLpfTaps / 2, n_hi = n_lo + kFir8Span;            // inputs [n_lo, n_hi)
     // the reference filters a zero-padded copy (360 leading zeros); outside the signal the products are zero
     if (n_lo < 0 || n_hi > kSigLen)
@@ -176,11 +188,21 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
             const int n = n_lo + e;
             if (n < 0 || n >= kSigLen) tile[(e & 7) * kFir8Pitch + (e >> 3)] = make_float2(0.0f, 0.0f);
         }
-    const int sym_lo = max(n_lo, 0) >> 8, sym_hi = (min(n_hi, kSigLen) - 1) >> 8;
+    // what this tile forms itself: an even tile all its inputs, an odd tile its own range only
+    const int c_lo = parity ? n0 : n_lo, c_hi = parity ? min(n0 + kFir8Out, n_hi) : n_hi;
+    if (parity) {
+        for (int e = tid; e < kFir8Span; e += kFirThreads) {
+            const int n = n_lo + e;
+            if (n < 0 || n >= kSigLen) continue;
+            if (n < n0) tile[(e & 7) * kFir8Pitch + (e >> 3)] = my_halo[-kHalo + (n - n_lo)];          // left neighbour's LAST 180
+            else if (n >= n0 + kFir8Out) tile[(e & 7) * kFir8Pitch + (e >> 3)] = my_halo[2 * kHalo + (n - (n0 + kFir8Out))];   // right neighbour's FIRST 180
+        }
+    }
+    const int sym_lo = max(c_lo, 0) >> 8, sym_hi = (min(c_hi, kSigLen) - 1) >> 8;
 #pragma unroll 1
     for (int sym = sym_lo; sym <= sym_hi; ++sym) {
         const int n = sym * kSps + tid;
-        if (n < n_lo || n >= n_hi) continue;                               // whole waves at a time except at the two ends
+        if (n < c_lo || n >= c_hi) continue;                               // whole waves at a time except at the two ends
         float phi;
         if (!dense) {
             const int r0 = __builtin_amdgcn_readfirstlane((int)tb.first_run[sym]);
@@ -206,22 +228,15 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
         }
         const int e = n - n_lo;
         tile[(e & 7) * kFir8Pitch + (e >> 3)] = make_float2(a, b);
-        if (n >= n0 && n < n0 + kFir8Out) rref[n - n0] = make_float2(cr, sr);
+        if (n >= n0 && n < n0 + kFir8Out) {
+            rref[n - n0] = make_float2(cr, sr);
+            if (!parity) {                                                 // what the odd neighbours will need
+                if (n - n0 < kHalo) my_halo[n - n0] = make_float2(a, b);
+                else if (n - n0 >= kFir8Out - kHalo) my_halo[kHalo + (n - n0) - (kFir8Out - kHalo)] = make_float2(a, b);
+            }
+        }
     }
     __syncthreads();
-    // The subtraction is IN PLACE and this workgroup has just read 180 samples on either side of its own outputs --
-    // samples its two neighbours will overwrite, as it will overwrite theirs.  Nobody may write before both
-    // neighbours have read: every workgroup raises a flag once its inputs are in LDS (all its loads have returned:
-    // their values were stored to LDS before the barrier above) and checks its neighbours' flags before its epilogue.
-    // The 21 workgroups of a job are dispatched back to back and staging is the first tenth of a workgroup's life, so
-    // the check normally passes at once; it cannot deadlock: only the last resident workgroup in dispatch order can
-    // wait for one that is not resident yet, and every other one finishes and frees its slot.
-    int* __restrict__ flags = staged + (size_t)blockIdx.y * gridDim.x;
-    // Relaxed, agent scope: nothing is PUBLISHED here -- the flag orders this workgroup's completed loads before its
-    // neighbours' later stores, and the barrier above already waited for those loads.  (A release store at agent
-    // scope writes the XCD's L2 back, 43 000 times per launch: measured 2.7 -> 4.0 ms per 2 048 jobs.)
-    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
     // outputs n0 + 8 tid + r, r = 0..7; input of tap j for output r: e = 8 tid + r + j
     v2f acc[8], x[8];
 #pragma unroll
@@ -271,12 +286,6 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (tid < 2) {                                           // thread 0: left neighbour, thread 1: right neighbour
-        const int nb = (int)blockIdx.x + (tid == 0 ? -1 : 1);
-        if (nb >= 0 && nb < (int)gridDim.x)
-            while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = n0 + 8 * tid + r;
@@ -374,19 +383,19 @@ void launch_subtract_symbolwise(float* dI, float* dQ, int samples, float f0, int
     hipLaunchKernelGGL(sub_symbolwise_kernel, dim3(kNSymD), dim3(kSps), 0, st, dI, dQ, samples, f0, shift, drift, d_sym);
 }
 
-// scratch floats needed for njobs jobs: the phase-run tables + one "inputs staged" flag per workgroup of the FIR
-constexpr int kFirWgs = (kSigLen + kFir8Out - 1) / kFir8Out;      // 21
-size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kTableFloats + kFirWgs); }
+// scratch floats needed for njobs jobs: the phase-run tables + the halos the even tiles save for the odd ones
+size_t subtract_scratch_floats(int njobs) { return (size_t)njobs * (kTableFloats + (size_t)kFirWgs * 2 * kHalo * 2); }
 
 void launch_subtract(float* dI, float* dQ, int samples, const SubJob* jobs, int njobs,
                      float* scratch, const DeviceTables& t, hipStream_t st) {
     if (njobs <= 0) return;
     PhaseTable* tables = reinterpret_cast<PhaseTable*>(scratch);
-    int* staged = reinterpret_cast<int*>(scratch + (size_t)njobs * kTableFloats);
-    (void)hipMemsetAsync(staged, 0, (size_t)njobs * kFirWgs * sizeof(int), st);
+    float2* halo = reinterpret_cast<float2*>(scratch + (size_t)njobs * kTableFloats);
     hipLaunchKernelGGL(sub_runs_wave_kernel, dim3(njobs), dim3(64), 0, st, jobs, njobs, tables);
-    hipLaunchKernelGGL(sub_fir_fused_kernel, dim3(kFirWgs, njobs), dim3(kFirThreads), 0, st,
-                       dI, dQ, samples, jobs, tables, t.lpf, t.lpf_part, staged);
+    hipLaunchKernelGGL(sub_fir_fused_kernel, dim3((kFirWgs + 1) / 2, njobs), dim3(kFirThreads), 0, st,
+                       dI, dQ, samples, jobs, tables, t.lpf, t.lpf_part, halo, 0);
+    hipLaunchKernelGGL(sub_fir_fused_kernel, dim3(kFirWgs / 2, njobs), dim3(kFirThreads), 0, st,
+                       dI, dQ, samples, jobs, tables, t.lpf, t.lpf_part, halo, 1);
 }
 
 // Working copy of resident input: rows of `samples` floats (16-byte aligned, stride a multiple of 4) into
