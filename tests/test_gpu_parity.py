@@ -251,8 +251,13 @@ def test_subtract_signal_symbolwise_bit_exact(w, synth_batch, seg, drift, shift_
     assert np.array_equal(outs[0][0][np_:], I[seg][np_:])          # nothing beyond np is touched
 
 
-@pytest.mark.parametrize("seg,drift,shift_off", [(0, 0.0, 0), (6, 0.0, 0), (7, 2.0, 0), (1, 0.0, -2500), (2, -1.0, 3900)])
-def test_subtract_signal2_bit_exact(w, synth_batch, seg, drift, shift_off):
+@pytest.mark.parametrize("seg,drift,shift_off,np_", [(0, 0.0, 0, NS), (6, 0.0, 0, NS), (7, 2.0, 0, NS), (1, 0.0, -2500, NS),
+                                                     (2, -1.0, 3900, NS), (3, 0.0, 0, 30000), (4, 1.0, -700, 41000),
+                                                     (5, 0.0, -41000, NS), (0, 0.0, 44000, NS)])
+def test_subtract_signal2_bit_exact(w, synth_batch, seg, drift, shift_off, np_):
+    """Incl. records shorter than the frame (np < 45000), frames hanging off either end by thousands of samples and
+    frames almost entirely outside the record: the fused kernel's tiles (2 048 outputs, even ones first, then the odd
+    ones with the halos the even ones saved) must reproduce the reference's edge handling (wsprd.c:370-404)."""
     I, Q, truth = synth_batch
     msg, f0, t0, snr = truth[seg][0]
     sym = symf(msg)
@@ -260,7 +265,7 @@ def test_subtract_signal2_bit_exact(w, synth_batch, seg, drift, shift_off):
     outs = []
     for which in ("gpu", "cpu"):
         Ic, Qc = I[seg].copy(), Q[seg].copy()
-        args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(NS), C.c_float(f0), C.c_int(shift), C.c_float(drift), ol.ptr(sym)]
+        args = [ol.ptr(Ic), ol.ptr(Qc), C.c_long(np_), C.c_float(f0), C.c_int(shift), C.c_float(drift), ol.ptr(sym)]
         (w.lib().subtract_signal2 if which == "gpu" else ol.lib().orc_subtract)(*args)
         outs.append((Ic, Qc))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
