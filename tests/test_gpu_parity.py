@@ -637,6 +637,19 @@ def test_wave_fano_equals_host_fano(w):
         assert 20 < nto < n - 20
 
 
+def test_wave_fano_with_a_small_stack_in_a_subprocess():
+    """K6w with a stack of 1 024 visits (test hook WSPR_FANO_WAVE_CAP, read once per process): the same vectors and the
+    same assertions as test_wave_fano_equals_host_fano, now through the narrowed steps and the LDS window's spills and
+    fills at those widths; a vector whose stack overflows all the same is finished by the host routine (exact)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WSPR_FANO_WAVE_CAP="1024")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_wave_fano_equals_host_fano"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:]
+
+
 def test_wave_fano_many_time_outs_throughput(w):
     """The crowded-band tail: thousands of undecodable vectors, full budget.  All time out exactly like
     the host routine says (sampled), in tens of milliseconds instead of ~5 ms of a CPU core each."""
