@@ -139,6 +139,14 @@ int wspr_decode_batch_trace(float *idat, float *qdat, int nseg, int samples, siz
 int wspr_decode_batch_node(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
                            struct decoder_options options, struct decoder_results *decodes,
                            int max_results, int *n_results, int ndevices);
+/* The same for IQ already RESIDENT on device `src_device` (rows of seg_stride floats, e.g. what
+ * wspr_decimate_u8_batch_device() left there): every other device pulls its wspr_shard_range() block over xGMI
+ * with a peer copy (the scatter of 360 000 B per segment for real inputs, here inside one process),
+ * decodes it on its own host thread and writes its spots into the caller's arrays.  The stream contract of
+ * wspr_decode_batch_device() applies to d_idat / d_qdat. */
+int wspr_decode_batch_node_device(const void *d_idat, const void *d_qdat, int src_device, int nseg, int samples,
+                                  size_t seg_stride, struct decoder_options options,
+                                  struct decoder_results *decodes, int max_results, int *n_results, int ndevices);
 /* The partitioning rule of the node-level call and of the multi-process driver (rtlsdr-wsprd_amd/dist.py
  * shard_range): shard k of n owns segments [*lo, *hi), the first nseg % n shards one segment more. */
 void wspr_shard_range(int nseg, int shard, int nshards, int *lo, int *hi);

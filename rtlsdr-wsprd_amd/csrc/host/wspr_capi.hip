@@ -256,6 +256,85 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
     return rc;
 }
 
+// The same fan-out for input that is already RESIDENT on one device (e.g. the front end's output on the GPU a
+// receiver bank feeds): every other device pulls its block of rows over xGMI with a peer copy (one process: a peer
+// DMA is what an ncclSend/ncclRecv pair between two devices of the same process comes down to), decodes it, and the
+// spots land in the caller's arrays.  SURVEY 8e: "for real inputs ... (scatter) of 360 000 B per segment".
+int wspr_decode_batch_node_device(const void* d_idat, const void* d_qdat, int src_device, int nseg, int samples,
+                                  size_t seg_stride, struct decoder_options options, struct decoder_results* decodes,
+                                  int max_results, int* n_results, int ndevices) {
+    const int count = wspr_device_count();
+    if (count <= 0 || src_device < 0 || src_device >= count) {
+        fprintf(stderr, "libwspr_mi355x: wspr_decode_batch_node_device: no such source device %d (%d visible)\n", src_device, count);
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return -1;
+    }
+    if (ndevices <= 0) ndevices = count;
+    const char* virt = getenv("WSPR_NODE_VIRTUAL");
+    const int per_dev = (ndevices + count - 1) / count;
+    if ((ndevices > count && !(virt && atoi(virt))) || ndevices > Context::kMaxDevices ||
+        Context::lane() + per_dev > Context::kUserLanes) {
+        fprintf(stderr, "libwspr_mi355x: wspr_decode_batch_node_device: %d devices asked for, %d visible\n", ndevices, count);
+        for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return -1;
+    }
+    int home = 0;
+    (void)hipGetDevice(&home);
+    const float* si = static_cast<const float*>(d_idat);
+    const float* sq = static_cast<const float*>(d_qdat);
+    if (options.usehashtable && nseg > 1) {              // ordered by definition: decoded where the data is
+        (void)hipSetDevice(src_device);
+        const int rc = wspr_decode_batch_device(si, sq, nseg, samples, seg_stride, options, decodes, max_results, n_results);
+        (void)hipSetDevice(home);
+        return rc;
+    }
+    int prev = wspr::node_share().load();
+    while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    const int lane0 = Context::lane();
+    std::vector<int> rcs(ndevices, 0);
+    std::vector<std::thread> th;
+    for (int k = 0; k < ndevices; ++k) {
+        int lo = 0, hi = 0;
+        wspr_shard_range(nseg, k, ndevices, &lo, &hi);
+        if (hi <= lo) continue;
+        th.emplace_back([=, &rcs] {
+            const int dev = k % count;
+            if (hipSetDevice(dev) != hipSuccess) { rcs[k] = -1; return; }
+            Context::bind_lane(lane0 + k / count);
+            const size_t off = (size_t)lo * seg_stride, floats = (size_t)(hi - lo) * seg_stride;
+            const float *pi = si + off, *pq = sq + off;
+            void *ti = nullptr, *tq = nullptr;
+            // (under the test hook every block but the first takes the copy path, also on the source device itself)
+            if (dev != src_device || (virt && atoi(virt) && k > 0)) {     // pull the block over xGMI
+                if (dev != src_device) {
+                    (void)hipDeviceEnablePeerAccess(src_device, 0);      // "already enabled" is fine
+                    (void)hipGetLastError();
+                }
+                if (hipMalloc(&ti, floats * 4) != hipSuccess || hipMalloc(&tq, floats * 4) != hipSuccess ||
+                    hipMemcpyPeer(ti, dev, pi, src_device, floats * 4) != hipSuccess ||
+                    hipMemcpyPeer(tq, dev, pq, src_device, floats * 4) != hipSuccess) {
+                    fprintf(stderr, "libwspr_mi355x: peer copy of segments %d..%d to device %d failed\n", lo, hi, dev);
+                    if (ti) (void)hipFree(ti);
+                    if (tq) (void)hipFree(tq);
+                    rcs[k] = -1;
+                    return;
+                }
+                pi = static_cast<const float*>(ti); pq = static_cast<const float*>(tq);
+            }
+            rcs[k] = wspr_decode_batch_device(pi, pq, hi - lo, samples, seg_stride, options,
+                                              decodes + (size_t)lo * max_results, max_results, n_results + lo);
+            if (ti) (void)hipFree(ti);
+            if (tq) (void)hipFree(tq);
+        });
+    }
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(home);
+    int rc = 0;
+    for (int k = 0; k < ndevices; ++k) if (rcs[k] < rc) rc = rcs[k];
+    if (rc < 0) for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+    return rc;
+}
+
 int wspr_decode(float* idat, float* qdat, int samples, struct decoder_options options,
                 struct decoder_results* decodes, int* n_results) {
     // the reference caller owns decodes[] with room for its own count (50 in rtlsdr_wsprd.c:117)

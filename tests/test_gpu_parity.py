@@ -765,3 +765,19 @@ def test_node_level_call_equals_one_device_batch(w, synth_batch, monkeypatch):
     lo, hi = C.c_int(), C.c_int()
     L.wspr_shard_range(8, 1, 3, C.byref(lo), C.byref(hi))
     assert (lo.value, hi.value) == (3, 6)
+    # ... and the same with the IQ resident on device 0 (blocks reach the other devices by peer copies)
+    import torch
+    torch.cuda.set_device(0)
+    dI = torch.from_numpy(I).cuda(); dQ = torch.from_numpy(Q).cuda()
+    w.sync_torch()
+    L.wspr_decode_batch_node_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, w.decoder_options,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    nseg = I.shape[0]
+    for nd in (1, 3 * ndev):
+        out = (w.decoder_results * (nseg * 16))(); nres = (C.c_int * nseg)()
+        assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), 0, nseg, NS, NS, w.default_options(),
+                                               C.addressof(out), 16, C.addressof(nres), nd) == 0
+        assert [[_spot_tuple(out[s * 16 + i]) for i in range(nres[s])] for s in range(nseg)] == want
+    out = (w.decoder_results * (nseg * 16))(); nres = (C.c_int * nseg)()
+    assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), ndev + 3, nseg, NS, NS, w.default_options(),
+                                           C.addressof(out), 16, C.addressof(nres), 0) == -1
