@@ -23,6 +23,7 @@ python tools/gpu_busy.py $(ls $O/c3/*/*kernel_trace.csv) 0.45 0.9 > $O/c3_gpu_bu
 tools/kprobe.sh $O/isolated 2048 1 > $O/isolated_kernels.txt 2>&1
 tools/sqprobe.sh $O/isolated_sq 2048 1 > $O/isolated_sq.txt 2>&1
 python tools/fano_latency.py > $O/k6w_latency.txt 2>&1
+[ -x tools/valu_issue_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Wno-unused-value tools/valu_issue_probe.hip -o tools/valu_issue_probe.bin
 tools/valu_issue_probe.bin > $O/valu_issue_probe.txt 2>&1
 tools/k0_cu_share.sh $O/k0_cus 2 > $O/k0_cu_share.txt 2>&1
 python tools/k0_scan.py 32 > $O/k0_alone.txt 2>&1
