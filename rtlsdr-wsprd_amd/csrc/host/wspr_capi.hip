@@ -312,7 +312,10 @@ int wspr_decode_batch_node_device(const void* d_idat, const void* d_qdat, int sr
                 }
                 if (hipMalloc(&ti, floats * 4) != hipSuccess || hipMalloc(&tq, floats * 4) != hipSuccess ||
                     hipMemcpyPeer(ti, dev, pi, src_device, floats * 4) != hipSuccess ||
-                    hipMemcpyPeer(tq, dev, pq, src_device, floats * 4) != hipSuccess) {
+                    hipMemcpyPeer(tq, dev, pq, src_device, floats * 4) != hipSuccess ||
+                    // a device-to-device copy may return before it has run, and the library's streams are
+                    // non-blocking (they do not wait for the null stream): wait here
+                    hipStreamSynchronize(nullptr) != hipSuccess) {
                     fprintf(stderr, "libwspr_mi355x: peer copy of segments %d..%d to device %d failed\n", lo, hi, dev);
                     if (ti) (void)hipFree(ti);
                     if (tq) (void)hipFree(tq);
