@@ -115,7 +115,7 @@ std::string url_escape(const char* s) {
 
 extern "C" {
 
-const char* wspr_mi355x_version(void) { return "wspr-mi355x 0.1 (gfx950, HIP)"; }
+const char* wspr_mi355x_version(void) { return "wspr-mi355x 0.3 (gfx950, HIP)"; }
 
 int wspr_device_ready(void) {
     try { Context::get(); return 1; } catch (const std::exception& e) { fail("wspr_device_ready", e); return 0; }
