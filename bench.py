@@ -187,6 +187,43 @@ def cpu_baseline(I_host, Q_host, expected, budget_s=25.0):
                       "segments/s" % (n, cores, os.cpu_count() or 0, 1.0 / one)}, res
 
 
+def measure_k1_traffic(nseg, nsig, timeout_s=150):
+    """HBM bytes of the FFT+sync stage's kernels from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE,
+    then WRITE_SIZE -- separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes) of tools/pmc_k1.py (a
+    1 GiB calibration copy + five launches of K1/K2/K3 on nseg resident segments) in child processes, summarised by
+    tools/pmc_summarise.py (gfx950: FETCH_SIZE counts half of the bytes read; calibrated on the copy).  Returns the
+    summary dict or None (no rocprofv3, a pass failed or timed out: the caller falls back to the round's profile)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    tmp = tempfile.mkdtemp(prefix="wspr_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    t_end = time.time() + timeout_s
+    try:
+        csvs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_k1.py"), str(nseg), str(nsig)], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=max(10.0, t_end - time.time()))
+            found = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not found:
+                return None
+            csvs[counter] = found[0]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summarise.py"), csvs["FETCH_SIZE"], csvs["WRITE_SIZE"],
+                            str(nseg)], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout) if r.returncode == 0 else None
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def k0_report(L, m, with_cpu=True):
     """Roofline of the front end (K0, the HBM-bound kernel of configs[4]) on the resident raw segments of measurement
     `m`, HIP events on the launch stream, and the decimator's CPU baseline (the oracle's restatement of
@@ -292,6 +329,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
     ap.add_argument("--no-tertiary", action="store_true", help="skip the configs[4] block of the N=1 line")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc passes (about 40 s); read it from profiles/")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
     ap.add_argument("--fano-fast", type=int, default=None,
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
@@ -509,7 +548,18 @@ def main():
         L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 5, C.addressof(ms))
         k1, k2, k3 = ms[0], ms[1], ms[2]
         traffic, traffic_src = None, None
-        for name in ("r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json"):
+        if world == 1 and not use_dist and not args.no_pmc and args.config in (2, 3):
+            # measured in this run (the verdict of round 2: a number read from profiles/ goes stale when a kernel changes)
+            pm = measure_k1_traffic(nseg, 10 if args.config == 3 else 1)
+            if pm and pm.get("hbm_bytes_per_segment"):
+                traffic = pm["hbm_bytes_per_segment"] * nseg
+                kk = pm["kernels"][pm["dominant_kernel"]]
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_k1.py "
+                               "%d %d; read %.3f GB + written %.3f GB per launch; FETCH_SIZE x %.3f, WRITE_SIZE x %.3f by the 1 GiB "
+                               "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
+                                         pm["calibration"]["true_bytes_per_counted_read_byte"],
+                                         pm["calibration"]["true_bytes_per_counted_written_byte"]))
+        for name in (() if traffic else ("r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
             tf = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tf):
                 jd = json.load(open(tf))
