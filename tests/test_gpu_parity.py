@@ -344,6 +344,41 @@ def test_randomised_scenes_equal_oracle(w):
     assert total > 40 and len(got[0]) == 0
 
 
+def crowded_scenes(count, seed=77):
+    """Bands the other generators do not produce: 12-40 signals inside +-112 Hz (many closer than one tone
+    spacing), -24..+12 dB, so that a segment yields dozens of candidates, repeated decodes of one signal and
+    more than sixteen spots."""
+    rng = np.random.default_rng(seed)
+    sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+    Is, Qs = [], []
+    for scene in range(count):
+        nsig = int(rng.integers(12, 41))
+        I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
+        f = np.sort(rng.uniform(-112, 112, nsig))
+        for k in range(nsig):
+            msg = synth.message_for(int(rng.integers(0, 1 << 20)))
+            amp = 10.0 ** (rng.uniform(-24, 12) / 20.0)
+            si, sq = synth.tone_signal(symf(msg), f[k], rng.uniform(0.5, 3.5), amp, drift=float(rng.integers(-2, 3)))
+            I += si; Q += sq
+        a, b = synth.normalise(I.astype(np.float32), Q.astype(np.float32))
+        Is.append(a); Qs.append(b)
+    return np.stack(Is), np.stack(Qs)
+
+
+@pytest.mark.parametrize("opts", [{}, {"npasses": 3}, {"subtraction": 0}, {"quickmode": 1}, {"npasses": 1}])
+def test_crowded_band_equals_oracle(w, opts):
+    """Crowded bands under every option set: spot for spot the oracle's (a longer soak: WSPR_CROWDED=200)."""
+    I, Q = crowded_scenes(int(os.environ.get("WSPR_CROWDED", "6")))
+    got = w.wspr_decode_batch(I, Q, w.default_options(**opts), max_results=100)
+    most = 0
+    for s in range(I.shape[0]):
+        ref, _, _ = ol.decode(I[s], Q[s], NS, ol.default_options(**opts))
+        assert [_spot_tuple(x) for x in got[s]] == [_spot_tuple(x) for x in ref], (s, opts)
+        assert all(abs(a.snr - b.snr) < 1e-4 for a, b in zip(got[s], ref))
+        most = max(most, len(ref))
+    assert most >= 8
+
+
 def test_committed_scene_spots_without_the_oracle(w):
     """The product against tests/golden/scene_spots.json alone (no oracle call in the loop): every field
     of every spot, SNR to the stated 0.1 dB."""
