@@ -538,19 +538,22 @@ void demod_lag3_kernel(const float* __restrict__ dI, const float* __restrict__ d
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int kbase = st.shift_coarse - 128 + kSps * sym0;
-    for (int e0 = tid; e0 < span; e0 += 4 * kL3Threads) {
-        float2 v[4];
+    // every load of the tile is issued before the first is waited for (one trip to memory instead of seven):
+    // addresses are clamped into the segment and the value is dropped where the reference skips the sample
+    constexpr int kIter = kL3Span / kL3Threads;               // 28 samples per lane
+    static_assert(kL3Span % kL3Threads == 0, "tile rows per lane");
+    float2 v[kIter];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * kL3Threads, k = kbase + e;
-            const bool ok = (e < span) && (k > 0) && (k < np);   // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
-            v[u] = ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f);
-        }
+    for (int u = 0; u < kIter; ++u) {
+        const int kc = min(max(kbase + tid + u * kL3Threads, 0), np - 1);
+        v[u] = make_float2(xi[kc], xq[kc]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * kL3Threads;
-            if (e < span) tile[(e & 7) * kL3Pitch + (e >> 3)] = v[u];
-        }
+    for (int u = 0; u < kIter; ++u) {
+        const int e = tid + u * kL3Threads, k = kbase + e;
+        const bool ok = (e < span) && (k > 0) && (k < np);   // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
+        tile[(e & 7) * kL3Pitch + (e >> 3)] = ok ? v[u] : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
     if (L >= kL3Lanes) return;
