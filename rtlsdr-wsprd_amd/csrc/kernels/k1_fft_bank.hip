@@ -56,23 +56,29 @@ __device__ __forceinline__ void bfly(v2& u, v2& v, const v2 w, const v2 wn) {
 }
 
 struct Tw {
-    v2 w[7], wn_[7];
-    __device__ __forceinline__ v2 wn(int k) const { return wn_[k]; }
+    v2 w[7];
+    // (-wy, wx): a swizzle and a sign of w, folded into the operand modifiers of the packed multiply
+    __device__ __forceinline__ v2 wn(int k) const { return v2{-w[k].y, w[k].x}; }
 };
-__device__ __forceinline__ void set_tw(Tw& t, int k, const float2 f) {
-    t.w[k] = v2{f.x, f.y};
-    t.wn_[k] = v2{-f.y, f.x};
+__device__ __forceinline__ void set_tw(Tw& t, int k, const float2 f) { t.w[k] = v2{f.x, f.y}; }
+
+// Four independent butterflies of one stage, issued operation by operation (all differences, all sums, all
+// products, ...): a packed result is never read by the very next instruction, which would cost a wait state each.
+__device__ __forceinline__ void bfly4(v2& u0, v2& v0, const v2 w0, const v2 n0, v2& u1, v2& v1, const v2 w1, const v2 n1,
+                                      v2& u2, v2& v2_, const v2 w2, const v2 n2, v2& u3, v2& v3, const v2 w3, const v2 n3) {
+    const v2 d0 = u0 - v0, d1 = u1 - v1, d2 = u2 - v2_, d3 = u3 - v3;
+    u0 = u0 + v0; u1 = u1 + v1; u2 = u2 + v2_; u3 = u3 + v3;
+    const v2 p0 = d0.xx * w0, p1 = d1.xx * w1, p2 = d2.xx * w2, p3 = d3.xx * w3;
+    const v2 q0 = d0.yy * n0, q1 = d1.yy * n1, q2 = d2.yy * n2, q3 = d3.yy * n3;
+    v0 = p0 + q0; v1 = p1 + q1; v2_ = p2 + q2; v3 = p3 + q3;
 }
 
 // three DIF stages on the 8 register-resident points; tw 0..3 stage a (pairs r,r+4),
 // 4..5 stage b (pairs r,r+2), 6 stage c (pairs r,r+1)
 __device__ __forceinline__ void pass3(v2 (&x)[8], const Tw& t) {
-    bfly(x[0], x[4], t.w[0], t.wn(0)); bfly(x[1], x[5], t.w[1], t.wn(1));
-    bfly(x[2], x[6], t.w[2], t.wn(2)); bfly(x[3], x[7], t.w[3], t.wn(3));
-    bfly(x[0], x[2], t.w[4], t.wn(4)); bfly(x[1], x[3], t.w[5], t.wn(5));
-    bfly(x[4], x[6], t.w[4], t.wn(4)); bfly(x[5], x[7], t.w[5], t.wn(5));
-    bfly(x[0], x[1], t.w[6], t.wn(6)); bfly(x[2], x[3], t.w[6], t.wn(6));
-    bfly(x[4], x[5], t.w[6], t.wn(6)); bfly(x[6], x[7], t.w[6], t.wn(6));
+    bfly4(x[0], x[4], t.w[0], t.wn(0), x[1], x[5], t.w[1], t.wn(1), x[2], x[6], t.w[2], t.wn(2), x[3], x[7], t.w[3], t.wn(3));
+    bfly4(x[0], x[2], t.w[4], t.wn(4), x[1], x[3], t.w[5], t.wn(5), x[4], x[6], t.w[4], t.wn(4), x[5], x[7], t.w[5], t.wn(5));
+    bfly4(x[0], x[1], t.w[6], t.wn(6), x[2], x[3], t.w[6], t.wn(6), x[4], x[5], t.w[6], t.wn(6), x[6], x[7], t.w[6], t.wn(6));
 }
 
 // The last three stages only meet the twiddles 1, -i and (1-i)/sqrt2, (-1-i)/sqrt2.  Written
@@ -102,28 +108,58 @@ __device__ __forceinline__ void bfly_w83(v2& u, v2& v, float c) {   // w = (-c, 
     v = v2{m.y, -m.x} + (-m);
 }
 __device__ __forceinline__ void pass3_last(v2 (&x)[8], float c) {
-    bfly_one(x[0], x[4]); bfly_w8(x[1], x[5], c); bfly_mi(x[2], x[6]); bfly_w83(x[3], x[7], c);
-    bfly_one(x[0], x[2]); bfly_mi(x[1], x[3]);    bfly_one(x[4], x[6]); bfly_mi(x[5], x[7]);
-    bfly_one(x[0], x[1]); bfly_one(x[2], x[3]);   bfly_one(x[4], x[5]); bfly_one(x[6], x[7]);
+    // the same butterflies, stage by stage with the independent operations of a stage side by side (see bfly4)
+    {   // stage a: (0,4) w = 1, (1,5) w8, (2,6) -i, (3,7) w83
+        const v2 d0 = x[0] - x[4], d1 = x[1] - x[5], d2 = x[2] - x[6], d3 = x[3] - x[7];
+        x[0] = x[0] + x[4]; x[1] = x[1] + x[5]; x[2] = x[2] + x[6]; x[3] = x[3] + x[7];
+        const v2 m1 = d1 * c, m3 = d3 * c;
+        x[4] = d0;
+        x[6] = v2{d2.y, -d2.x};
+        x[5] = m1 + v2{m1.y, -m1.x};
+        x[7] = v2{m3.y, -m3.x} + (-m3);
+    }
+    {   // stage b: (0,2) 1, (1,3) -i, (4,6) 1, (5,7) -i
+        const v2 d0 = x[0] - x[2], d1 = x[1] - x[3], d2 = x[4] - x[6], d3 = x[5] - x[7];
+        x[0] = x[0] + x[2]; x[1] = x[1] + x[3]; x[4] = x[4] + x[6]; x[5] = x[5] + x[7];
+        x[2] = d0; x[6] = d2;
+        x[3] = v2{d1.y, -d1.x};
+        x[7] = v2{d3.y, -d3.x};
+    }
+    {   // stage c: all w = 1
+        const v2 d0 = x[0] - x[1], d1 = x[2] - x[3], d2 = x[4] - x[5], d3 = x[6] - x[7];
+        x[0] = x[0] + x[1]; x[2] = x[2] + x[3]; x[4] = x[4] + x[5]; x[6] = x[6] + x[7];
+        x[1] = d0; x[3] = d1; x[5] = d2; x[7] = d3;
+    }
 }
 
 __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 
+struct OutCols { int base, at1, at6; };                      // see out_columns()
+constexpr int kOutSpill = 64 + 32;                           // floats behind the output tile (lane + time offset)
+__device__ constexpr int kOutRow[8] = {208, -48, 336, 80, 272, 16, 400, 144};
+
 // One FFT of the run: window, 3 passes, power into the workgroup's output tile.  `raw` is the sliding
 // window of raw samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block
 // instead of moving registers needs the run loop unrolled by 4 (kBase is a compile-time constant).
-template <int kBase, int kPitch, bool kBarrierBeforeWrite = false>
+template <int kBase, int kPitch, bool kBarrierBeforeWrite = false, bool kRefill = false>
 __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], const Tw& twA, const Tw& twB, float w8,
                                         v2* __restrict__ X, int lane, int a, int c,
                                         const float* __restrict__ si, const float* __restrict__ sq, int t, bool more,
-                                        float* __restrict__ otile, const int (&ocol)[8], int tl) {
+                                        float* __restrict__ otile, const OutCols ocol, int tl) {
     v2 x[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = raw[(kBase + r) & 7] * win[r];
 
-    // slide the raw window by one hop (two 64-sample rows) while the FFT runs
-    if (more) {
-        const int k = kHop * (t + 1) + 384 + lane;
+    // slide the raw window by one hop (two 64-sample rows) while the FFT runs; the last FFT of a group (kRefill)
+    // fetches the whole first window of the wave's next group instead: block t, rows 0..7 into raw[0..7]
+    // (no branch around the loads -- it would make the compiler copy the whole window at every FFT: where nothing
+    // follows, `more` is false and block 0 is fetched and never used)
+    if (kRefill) {
+        const int k0 = more ? kHop * t + lane : lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) raw[r] = v2{si[k0 + 64 * r], sq[k0 + 64 * r]};
+    } else {
+        const int k = more ? kHop * (t + 1) + 384 + lane : lane;
         raw[(kBase + 0) & 7] = v2{si[k], sq[k]};
         raw[(kBase + 1) & 7] = v2{si[k + 64], sq[k + 64]};
     }
@@ -146,29 +182,31 @@ __device__ __forceinline__ void one_fft(v2 (&raw)[8], const float (&win)[8], con
 
     pass3_last(x, w8);
 
-    // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane); ocol[r] = its row offset in the output
-    // tile, or negative for the bins nobody reads (out_columns())
+    // x[r] now holds bin rev9(8*lane + r) = 64*rev3(r) + rev6(lane); see OutCols for its row in the output tile
     if (kBarrierBeforeWrite) __syncthreads();       // fused kernel: the previous group's tile has been consumed
+    float* __restrict__ ob = otile + tl;                            // 64 lanes -> 64 different bins: 2 lanes per bank
+    v2 e[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = x[r] * x[r];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        if (ocol[r] >= 0) {
-            const v2 e = x[r] * x[r];
-            otile[ocol[r] + tl] = e.x + e.y;                    // 64 lanes -> 64 different bins: 2 lanes per bank
-        }
+        const float pw = e[r].x + e[r].y;
+        if (r == 1)      ob[ocol.at1] = pw;
+        else if (r == 6) ob[ocol.at6] = pw;
+        else ob[ocol.base + kOutRow[r] * kPitch] = pw;
     }
 }
 
-// tile row offset of register r's bin for this lane (fft-shifted bins 48..464 are kept), else -1
+// Where register r's bin goes.  With lo = rev6(lane), x[r] is natural bin 64 rev3(r) + lo; fft-shifted (+256 mod 512)
+// and counted from bin 48 (the first one kept) that is tile row lo + kOutRow[r].  Six of the eight rows exist for
+// every lane; r = 1 (row lo - 48) only for lo >= 48, r = 6 (row lo + 400) only below row 417, i.e. lo < 17.  A lane
+// without such a row writes its value to a word of its own behind the tile instead (kOutSpill floats): no branch.
 template <int kPitch>
-__device__ __forceinline__ void out_columns(int lane, int (&ocol)[8]) {
+__device__ __forceinline__ OutCols out_columns(int lane) {
+    static_assert(kPsBin0 == 48 && kPsBins == 417 && kFftSize == 512, "kOutRow is written for bins 48..464 of 512");
     const int lo = (int)rev6((unsigned)lane);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
-        const int bin = ((64 * rev3 + lo) + kFftSize / 2) & (kFftSize - 1);   // fft-shift
-        const int col = bin - kPsBin0;
-        ocol[r] = (col >= 0 && col < kPsBins) ? col * kPitch : -1;
-    }
+    const int spill = kPsBins * kPitch + lane;
+    return OutCols{lo * kPitch, lo >= 48 ? (lo + kOutRow[1]) * kPitch : spill, lo < 17 ? (lo + kOutRow[6]) * kPitch : spill};
 }
 
 template <int kRun>
@@ -207,8 +245,7 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
         set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
         set_tw(twB, 6, twiddle[32 * c]);
         const float w8 = twiddle[64].x;                 // cos(pi/4) as float; twiddle[64] = (w8, -w8)
-        int ocol[8];
-        out_columns<kOutPitch>(lane, ocol);
+        const OutCols ocol = out_columns<kOutPitch>(lane);
 
         v2 raw[8];
 #pragma unroll
@@ -255,7 +292,7 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
 // the stage's HBM traffic drops from IQ + 2 x ps to IQ + ps.  A wave's four blocks are consecutive (sliding
 // sample window inside the group); between groups the window is reloaded (the rows come from the caches).
 template <int kRun>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 47 KB of LDS: three workgroups per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
                          const int* __restrict__ seg_list, int blocks, float* __restrict__ ps,
                          float* __restrict__ psavg, const float* __restrict__ window,
@@ -285,8 +322,7 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     set_tw(twB, 4, twiddle[16 * c]);   set_tw(twB, 5, twiddle[128 + 16 * c]);
     set_tw(twB, 6, twiddle[32 * c]);
     const float w8 = twiddle[64].x;
-    int ocol[8];
-    out_columns<kOutPitch>(lane, ocol);
+    const OutCols ocol = out_columns<kOutPitch>(lane);
 
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int kParts = kWgTimes / 4;
@@ -294,23 +330,21 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     const int b_lo = threadIdx.x, b_hi = threadIdx.x + 256;              // the bins this thread averages
     float acc_lo = 0.0f, acc_hi = 0.0f;
 
-    // the first window of a group is fetched while the previous group's tile is stored and averaged
-    v2 nxt[8];
+    // a wave's window of raw samples lives across groups: the last FFT of a group refills it for the next one
+    v2 raw[8];
     {
         const int tb = wave * kRun;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k = kHop * min(tb, blocks - 1) + 64 * r + lane;
-            nxt[r] = v2{si[k], sq[k]};
+            raw[r] = v2{si[k], sq[k]};
         }
     }
     for (int t0 = 0; t0 < blocks; t0 += kWgTimes) {
         const int t_begin = t0 + wave * kRun;
         const int t_end = min(t_begin + kRun, blocks);
+        const int t_next = t_begin + kWgTimes;                          // this wave's first block of the next group
         if (t_begin < t_end) {
-            v2 raw[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) raw[r] = nxt[r];
             static_assert(kRun == 4, "the group loop below is written for four blocks per wave");
             // the barrier that frees the tile sits inside the first FFT, just before its powers are written:
             // a wave that is done with the previous tile starts computing at once
@@ -319,20 +353,10 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
                 one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 1, t_begin + 2 < t_end, otile, ocol, t_begin + 1 - t0);
             if (t_begin + 2 < t_end)
                 one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 2, t_begin + 3 < t_end, otile, ocol, t_begin + 2 - t0);
-            if (t_begin + 3 < t_end)
-                one_fft<6, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 3, false, otile, ocol, t_begin + 3 - t0);
+            if (t_begin + 3 < t_end)        // (a group with fewer than four blocks for this wave is the last one)
+                one_fft<6, kOutPitch, false, true>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_next, t_next < blocks, otile, ocol, t_begin + 3 - t0);
         } else {
             __syncthreads();
-        }
-        {
-            const int tb = t_begin + kWgTimes;
-            if (tb < blocks) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int k = kHop * tb + 64 * r + lane;
-                    nxt[r] = v2{si[k], sq[k]};
-                }
-            }
         }
         __syncthreads();                                               // the group's tile is complete
         const int nt = min(kWgTimes, blocks - t0);
@@ -459,7 +483,7 @@ void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int 
     // 1024 segments.
     constexpr int R = 4;
     constexpr int per_wg = R * kWavesPerWg;
-    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (per_wg + 1) * sizeof(float);
+    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + ((size_t)kPsBins * (per_wg + 1) + kOutSpill) * sizeof(float);
     static std::atomic<unsigned> opted{0};
     lds_opt_in(reinterpret_cast<const void*>(&fft_bank_kernel<R>), lds, opted);
     dim3 grid((blocks + per_wg - 1) / per_wg, nseg_active);
@@ -473,7 +497,7 @@ void launch_fft_bank_avg(const float* dI, const float* dQ, const int* seg_list, 
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (blocks <= 0 || nseg_active <= 0) return;
     constexpr int R = 4;
-    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + (size_t)kPsBins * (R * kWavesPerWg + 1) * sizeof(float);
+    const size_t lds = kWavesPerWg * kTile * sizeof(v2) + ((size_t)kPsBins * (R * kWavesPerWg + 1) + kOutSpill) * sizeof(float);
     hipLaunchKernelGGL(fft_bank_avg_kernel<R>, dim3(nseg_active), dim3(256), lds, st, dI, dQ, seg_list, blocks, ps,
                        psavg, t.window, t.twiddle);
 }
