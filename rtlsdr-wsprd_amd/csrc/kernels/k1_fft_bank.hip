@@ -134,9 +134,19 @@ __device__ __forceinline__ void pass3_last(v2 (&x)[8], float c) {
 
 __device__ __forceinline__ unsigned rev6(unsigned v) { return __brev(v) >> 26; }
 
+// Rows of the output tile whose bin index has bit 5 set start one word late.  A ds_write_b32 is served in two groups
+// of 32 lanes on 32 banks, and the first 32 lanes hold the EVEN lo (bit-reversed lane numbers): with the odd pitch
+// alone their rows fall on 16 banks, two lanes each; rows 32 apart now differ by one bank and the 32 rows of a group
+// cover all 32.  (A row has 16 values in 17 words, so the skew stays inside it.)
+__device__ __forceinline__ int out_skew(int row) { return (row >> 5) & 1; }
 struct OutCols { int base, at1, at6; };                      // see out_columns()
 constexpr int kOutSpill = 64 + 32;                           // floats behind the output tile (lane + time offset)
 __device__ constexpr int kOutRow[8] = {208, -48, 336, 80, 272, 16, 400, 144};
+constexpr bool out_rows_share_a_skew() {
+    for (int r = 0; r < 8; ++r) if (((kOutRow[r] % 64) + 64) % 64 != 16) return false;
+    return true;
+}
+static_assert(out_rows_share_a_skew(), "every kOutRow[r] is 16 mod 64: one skew serves the eight rows of a lane");
 
 // One FFT of the run: window, 3 passes, power into the workgroup's output tile.  `raw` is the sliding
 // window of raw samples, raw[(base + r) & 7] = row r of this block; rotating `base` by 2 per block
@@ -206,7 +216,9 @@ __device__ __forceinline__ OutCols out_columns(int lane) {
     static_assert(kPsBin0 == 48 && kPsBins == 417 && kFftSize == 512, "kOutRow is written for bins 48..464 of 512");
     const int lo = (int)rev6((unsigned)lane);
     const int spill = kPsBins * kPitch + lane;
-    return OutCols{lo * kPitch, lo >= 48 ? (lo + kOutRow[1]) * kPitch : spill, lo < 17 ? (lo + kOutRow[6]) * kPitch : spill};
+    const int sk = out_skew(lo + 16);                // every kOutRow[r] is 16 mod 64: one skew for the lane's eight rows
+    return OutCols{lo * kPitch + sk, lo >= 48 ? (lo + kOutRow[1]) * kPitch + sk : spill,
+                   lo < 17 ? (lo + kOutRow[6]) * kPitch + sk : spill};
 }
 
 template <int kRun>
@@ -275,13 +287,106 @@ void fft_bank_kernel(const float* __restrict__ dI, const float* __restrict__ dQ,
         const int b = e / kParts, part = e - b * kParts;
         const int tl = 4 * part;
         if (t0 + tl >= blocks) continue;
-        const float* __restrict__ src = otile + b * kOutPitch + tl;
+        const float* __restrict__ src = otile + b * kOutPitch + out_skew(b) + tl;
         f4 v;
         v.x = src[0];
         v.y = (t0 + tl + 1 < blocks) ? src[1] : 0.0f;
         v.z = (t0 + tl + 2 < blocks) ? src[2] : 0.0f;
         v.w = (t0 + tl + 3 < blocks) ? src[3] : 0.0f;
         __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (size_t)b * kPsTPitch + tl));
+    }
+}
+
+// Two consecutive FFTs of a wave in lockstep (fused kernel).  A lone FFT stalls twice on its own transposes: eight LDS
+// writes, eight reads, and nothing to do until they return.  Here the two take turns: while one's transposed points
+// are on their way back from the LDS the other runs a register pass, so each read has ~75 packed instructions to
+// land under.  One tile serves both: the LDS executes a wave's accesses in issue order, so B's writes cannot pass
+// A's reads.  `S` is the wave's window of raw rows for one group of four FFTs: slot i holds row i (64 samples) of
+// the group's first block, rows 10..13 replace rows 0..3 once the first pair has been windowed (kFirst = 0), and
+// the next group's rows 0..9 are fetched once the second pair has (kFirst = 4).  obA/obB: the tile columns of the two
+// powers; where the second FFT does not exist (the segment's last blocks) it runs on clamped rows and writes nothing.
+template <int kFirst, int kPitch, bool kBarrierBeforeWrite>
+__device__ __forceinline__ void fft_pair(v2 (&S)[10], const float (&win)[8], const Tw& twA, const Tw& twB, float w8,
+                                         v2* __restrict__ X, int lane, int a, int c,
+                                         const float* __restrict__ si, const float* __restrict__ sq, int k_next,
+                                         float* __restrict__ obA, float* __restrict__ obB, bool has_b, const OutCols ocol) {
+    v2 xa[8], xb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        xa[r] = S[(kFirst + r) % 10] * win[r];
+        xb[r] = S[(kFirst + 2 + r) % 10] * win[r];
+    }
+    // rows that follow: no branch, one clamp of the (wave-uniform) start.  Rows a real FFT needs never reach the
+    // clamp (they end inside the segment's samples, and a row of the buffers is kIqStride floats: the clamp only
+    // moves fetches that lie wholly behind the last block, whose values are never used)
+    constexpr int kRows = kFirst == 0 ? 4 : 10;
+    const float* __restrict__ pi = si + (min(k_next, kIqStride - 64 * kRows) + lane);
+    const float* __restrict__ pq = sq + (min(k_next, kIqStride - 64 * kRows) + lane);
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) S[i] = v2{pi[64 * i], pq[64 * i]};
+    pass3(xa, twA);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * r + lane] = xa[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xa[r] = X[72 * a + 8 * r + c];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    pass3(xb, twA);                                    // ... while A's points come back
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * r + lane] = xb[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[r] = X[72 * a + 8 * r + c];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    pass3(xa, twB);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * a + 9 * r + c] = xa[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xa[r] = X[9 * lane + r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    pass3(xb, twB);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[72 * a + 9 * r + c] = xb[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[r] = X[9 * lane + r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    pass3_last(xa, w8);
+    if (kBarrierBeforeWrite) __syncthreads();       // the previous group's tile has been consumed
+    {
+        v2 e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = xa[r] * xa[r];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float pw = e[r].x + e[r].y;
+            if (r == 1)      obA[ocol.at1] = pw;
+            else if (r == 6) obA[ocol.at6] = pw;
+            else obA[ocol.base + kOutRow[r] * kPitch] = pw;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pass3_last(xb, w8);
+    if (has_b) {                                     // wave-uniform
+        v2 e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = xb[r] * xb[r];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float pw = e[r].x + e[r].y;
+            if (r == 1)      obB[ocol.at1] = pw;
+            else if (r == 6) obB[ocol.at6] = pw;
+            else obB[ocol.base + kOutRow[r] * kPitch] = pw;
+        }
     }
 }
 
@@ -302,7 +407,7 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     float* otile = reinterpret_cast<float*>(k1_smem + kWavesPerWg * kTile * sizeof(v2));
     constexpr int kWgTimes = kWavesPerWg * kRun;
     constexpr int kOutPitch = kWgTimes + 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int seg = seg_list ? seg_list[blockIdx.x] : (int)blockIdx.x;
     const float* __restrict__ si = dI + (size_t)seg * kIqStride;
     const float* __restrict__ sq = dQ + (size_t)seg * kIqStride;
@@ -328,33 +433,29 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
     constexpr int kParts = kWgTimes / 4;
     float* __restrict__ out_seg = ps + (size_t)seg * kPsBins * kPsTPitch;
     const int b_lo = threadIdx.x, b_hi = threadIdx.x + 256;              // the bins this thread averages
-    float acc_lo = 0.0f, acc_hi = 0.0f;
+    const int b_hi2 = min(b_hi, kPsBins - 1);
+    v2 acc = {0.0f, 0.0f};
 
-    // a wave's window of raw samples lives across groups: the last FFT of a group refills it for the next one
-    v2 raw[8];
+    // a wave's window of raw rows lives across groups (see fft_pair)
+    v2 S[10];
     {
-        const int tb = wave * kRun;
+        const int k0 = min(kHop * (wave * kRun), kIqStride - 640) + lane;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = kHop * min(tb, blocks - 1) + 64 * r + lane;
-            raw[r] = v2{si[k], sq[k]};
-        }
+        for (int i = 0; i < 10; ++i) S[i] = v2{si[k0 + 64 * i], sq[k0 + 64 * i]};
     }
     for (int t0 = 0; t0 < blocks; t0 += kWgTimes) {
         const int t_begin = t0 + wave * kRun;
-        const int t_end = min(t_begin + kRun, blocks);
-        const int t_next = t_begin + kWgTimes;                          // this wave's first block of the next group
-        if (t_begin < t_end) {
-            static_assert(kRun == 4, "the group loop below is written for four blocks per wave");
-            // the barrier that frees the tile sits inside the first FFT, just before its powers are written:
+        const int n_here = min(kRun, blocks - t_begin);                 // FFTs this wave has in the group (<= 0: none)
+        if (n_here > 0) {
+            static_assert(kRun == 4, "a group is two pairs of FFTs per wave");
+            float* const ob = otile + (t_begin - t0);
+            // the barrier that frees the tile sits inside the first pair, just before its first powers are written:
             // a wave that is done with the previous tile starts computing at once
-            one_fft<0, kOutPitch, true>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin, t_begin + 1 < t_end, otile, ocol, t_begin - t0);
-            if (t_begin + 1 < t_end)
-                one_fft<2, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 1, t_begin + 2 < t_end, otile, ocol, t_begin + 1 - t0);
-            if (t_begin + 2 < t_end)
-                one_fft<4, kOutPitch>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_begin + 2, t_begin + 3 < t_end, otile, ocol, t_begin + 2 - t0);
-            if (t_begin + 3 < t_end)        // (a group with fewer than four blocks for this wave is the last one)
-                one_fft<6, kOutPitch, false, true>(raw, win, twA, twB, w8, X, lane, a, c, si, sq, t_next, t_next < blocks, otile, ocol, t_begin + 3 - t0);
+            fft_pair<0, kOutPitch, true>(S, win, twA, twB, w8, X, lane, a, c, si, sq, kHop * t_begin + 640,
+                                         ob, ob + 1, n_here >= 2, ocol);
+            if (n_here >= 3)        // (a group with fewer blocks for this wave is the segment's last: nothing to refill)
+                fft_pair<4, kOutPitch, false>(S, win, twA, twB, w8, X, lane, a, c, si, sq, kHop * (t_begin + kWgTimes),
+                                              ob + 2, ob + 3, n_here >= 4, ocol);
         } else {
             __syncthreads();
         }
@@ -364,36 +465,43 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
         // if0 in [106, 406], and reads bins if0 - 6 .. if0 + 4 = 100 .. 410; the 106 rows outside were needed
         // for the time average alone, which this kernel forms itself.
         constexpr int kRowLo = 100 - kPsBin0, kRowHi = 410 - kPsBin0;
-        for (int e = threadIdx.x + kRowLo * kParts; e < (kRowHi + 1) * kParts; e += 256) {
-            const int b = e / kParts, part = e - b * kParts;
-            const int tl = 4 * part;
-            if (tl >= nt) continue;
-            const float* __restrict__ src = otile + b * kOutPitch + tl;
-            f4 v;
-            v.x = src[0];
-            v.y = (tl + 1 < nt) ? src[1] : 0.0f;
-            v.z = (tl + 2 < nt) ? src[2] : 0.0f;
-            v.w = (tl + 3 < nt) ? src[3] : 0.0f;
-            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out_seg + (size_t)b * kPsTPitch + t0 + tl));
+        static_assert(kParts == 4, "the store loop splits a row piece into four 16-byte words");
+        if (nt == kWgTimes) {                                          // every group but the segment's last
+#pragma unroll 1
+            for (int e = threadIdx.x + kRowLo * kParts; e < (kRowHi + 1) * kParts; e += 256) {
+                const int b = e >> 2, tl = 4 * (e & 3);
+                const float* __restrict__ src = otile + b * kOutPitch + out_skew(b) + tl;
+                const f4 v = {src[0], src[1], src[2], src[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out_seg + (size_t)b * kPsTPitch + t0 + tl));
+            }
+        } else {
+            for (int e = threadIdx.x + kRowLo * kParts; e < (kRowHi + 1) * kParts; e += 256) {
+                const int b = e >> 2, tl = 4 * (e & 3);
+                if (tl >= nt) continue;
+                const float* __restrict__ src = otile + b * kOutPitch + out_skew(b) + tl;
+                f4 v;
+                v.x = src[0];
+                v.y = (tl + 1 < nt) ? src[1] : 0.0f;
+                v.z = (tl + 2 < nt) ? src[2] : 0.0f;
+                v.w = (tl + 3 < nt) ? src[3] : 0.0f;
+                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out_seg + (size_t)b * kPsTPitch + t0 + tl));
+            }
         }
         {
-            const float* __restrict__ m0 = otile + b_lo * kOutPitch;
-            const float* __restrict__ m1 = otile + b_hi * kOutPitch;
+            // the two running sums of a thread advance together, one packed add per time block (each half is the
+            // reference's serial sum; threads without a second bin carry a copy of bin 416 along and drop it)
+            const float* __restrict__ m0 = otile + b_lo * kOutPitch + out_skew(b_lo);
+            const float* __restrict__ m1 = otile + b_hi2 * kOutPitch + out_skew(b_hi2);
             if (nt == kWgTimes) {
 #pragma unroll
-                for (int j = 0; j < kWgTimes; ++j) acc_lo += m0[j];
-                if (b_hi < kPsBins) {
-#pragma unroll
-                    for (int j = 0; j < kWgTimes; ++j) acc_hi += m1[j];
-                }
+                for (int j = 0; j < kWgTimes; ++j) acc = acc + v2{m0[j], m1[j]};
             } else {
-                for (int j = 0; j < nt; ++j) acc_lo += m0[j];
-                if (b_hi < kPsBins) for (int j = 0; j < nt; ++j) acc_hi += m1[j];
+                for (int j = 0; j < nt; ++j) acc = acc + v2{m0[j], m1[j]};
             }
         }
     }
-    psavg[(size_t)seg * kPsStride + b_lo] = acc_lo;
-    if (b_hi < kPsBins) psavg[(size_t)seg * kPsStride + b_hi] = acc_hi;
+    psavg[(size_t)seg * kPsStride + b_lo] = acc.x;
+    if (b_hi < kPsBins) psavg[(size_t)seg * kPsStride + b_hi] = acc.y;
 }
 
 }  // namespace
