@@ -15,6 +15,7 @@ cp $O/k1_pmc_traffic_1024.json $P/${R}_k1_pmc_traffic_1024seg.json
 cp $O/isolated_kernels.txt $P/${R}_isolated_launch_sets_kernel_times.txt
 cp $O/isolated_sq.txt $P/${R}_isolated_launch_sets_sq_counters.txt
 cp $O/k6w_latency.txt $P/${R}_k6w_latency.txt
+cp $O/k1_sq.txt $P/${R}_k1_sq_counters.txt
 cp $O/valu_issue_probe.txt $P/${R}_packed_fp32_issue_rate_by_occupancy.txt
 cp $O/k0_cu_share.txt $P/${R}_k0_cu_share_sweep.txt
 cp $O/k0_alone.txt $P/${R}_k0_alone.txt

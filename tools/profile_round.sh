@@ -22,6 +22,7 @@ python tools/gpu_busy.py $(ls $O/c3/*/*kernel_trace.csv) 0.45 0.9 > $O/c3_gpu_bu
 # isolated launch sets: per-kernel durations and SQ counters (2 048 single-signal candidates)
 tools/kprobe.sh $O/isolated 2048 1 > $O/isolated_kernels.txt 2>&1
 tools/sqprobe.sh $O/isolated_sq 2048 1 > $O/isolated_sq.txt 2>&1
+bash tools/k1_sq.sh > $O/k1_sq.txt 2>&1
 python tools/fano_latency.py > $O/k6w_latency.txt 2>&1
 [ -x tools/valu_issue_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Wno-unused-value tools/valu_issue_probe.hip -o tools/valu_issue_probe.bin
 tools/valu_issue_probe.bin > $O/valu_issue_probe.txt 2>&1
