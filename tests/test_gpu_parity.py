@@ -161,14 +161,58 @@ def test_coarse_sync_of_a_large_batch_matches_oracle(w, synth_batch, ref_iq, max
     assert rc == 0
     L = ol.lib()
     for s0 in range(n0):
-        onpk, oc, _, _ = _oracle_cands(I0[s0], Q0[s0], 0)
+        onpk, oc, onoise, osm = _oracle_cands(I0[s0], Q0[s0], 0)
         L.orc_coarse_sync(ol.ptr(oracle_ps(I0[s0], Q0[s0])), C.c_int(347), oc, C.c_int(onpk), C.c_int(maxdrift))
         for rep in range(reps):
             s = rep * n0 + s0
             assert npk[s] == onpk
+            # the time average comes from the FUSED K1 here (one workgroup per segment, pairs of FFTs per wave)
+            assert noise[s] == np.float32(onoise) and np.array_equal(sm[s], osm), s
             for j in range(onpk):
                 g, o = cands[200 * s + j], oc[j]
-                assert (g.freq, g.shift, g.drift, g.sync) == (o.freq, o.shift, o.drift, o.sync), (s, j)
+                assert (g.freq, g.shift, g.drift, g.sync, g.snr) == (o.freq, o.shift, o.drift, o.sync, o.snr), (s, j)
+
+
+@pytest.mark.parametrize("samples", [40000, 44992, 2048, 1024])
+def test_short_records_through_the_fused_fft_bank(w, synth_batch, ref_iq, samples):
+    """Records shorter than 45 000 samples in a batch large enough for the fused K1 (>= 256 segments): the last group
+    of time blocks is partial (waves with three blocks, or none), windows are fetched up to the end of the row.
+    Peak picker inputs (time average -> smoothed spectrum, noise) and candidates equal the oracle's on the same
+    truncated record."""
+    I0 = np.concatenate([ref_iq[0][None], synth_batch[0]])[:, :samples].copy()
+    Q0 = np.concatenate([ref_iq[1][None], synth_batch[1]])[:, :samples].copy()
+    n0 = I0.shape[0]
+    reps = -(-256 // n0)
+    I = np.tile(I0, (reps, 1)); Q = np.tile(Q0, (reps, 1))
+    nseg = I.shape[0]
+    cands = (w.cand * (200 * nseg))()
+    npk = (C.c_int * nseg)()
+    noise = np.zeros(nseg, np.float32)
+    sm = np.zeros((nseg, 411), np.float32)
+    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, samples, samples, 0, 4, C.addressof(cands),
+                                       C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
+    assert rc == 0
+    L = ol.lib()
+    blocks = 4 * (samples // 512) - 1
+    for s0 in range(n0):
+        ps = np.zeros((512, blocks), np.float32)
+        assert L.orc_blocks_for(samples) == blocks
+        # the reference's last block ends at 512 floor(samples / 512) + 255, which may lie behind `samples`
+        # (wsprd.c:536-542): its caller's buffers hold 45 000 samples, zeros behind the record -- the oracle
+        # gets such a buffer, the product zero-fills its own rows
+        Iz = np.concatenate([I0[s0], np.zeros(NS - samples, np.float32)])
+        Qz = np.concatenate([Q0[s0], np.zeros(NS - samples, np.float32)])
+        L.orc_fft_bank(ol.ptr(Iz), ol.ptr(Qz), C.c_int(samples), ol.ptr(ps))
+        oc = (ol.Cand * 200)()
+        onoise = C.c_float()
+        osm = np.zeros(411, np.float32)
+        onpk = L.orc_pick_peaks(ol.ptr(ps), C.c_int(blocks), oc, C.byref(onoise), ol.ptr(osm), None)
+        for rep in range(reps):
+            s = rep * n0 + s0
+            assert npk[s] == onpk, (s, samples)
+            assert noise[s] == np.float32(onoise.value) and np.array_equal(sm[s], osm), (s, samples)
+            for j in range(onpk):
+                assert (cands[200 * s + j].freq, cands[200 * s + j].snr) == (oc[j].freq, oc[j].snr), (s, j)
 
 
 # ------------------------------------------------------------------ K4 / K5
