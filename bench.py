@@ -545,7 +545,7 @@ def main():
         I, Q = m["I"], m["Q"]
         # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
         ms = (C.c_double * 8)()
-        L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 5, C.addressof(ms))
+        L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 10, C.addressof(ms))
         k1, k2, k3 = ms[0], ms[1], ms[2]
         traffic, traffic_src = None, None
         if world == 1 and not use_dist and not args.no_pmc and args.config in (2, 3):

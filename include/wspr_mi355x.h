@@ -272,7 +272,7 @@ int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int sa
  * the number of values written (<= capacity). */
 int wspr_last_timings(double *ms, int capacity);
 /* Times `iters` passes of the FFT+sync stage (K1,K2,K3) on resident data with HIP events on the
- * launch stream.  ms must hold 8 doubles: ms[0] = K1 (sum over the segment chunks of a pass),
+ * launch stream, after one untimed pass.  ms must hold 8 doubles: ms[0] = K1 (sum over the segment chunks of a pass),
  * ms[1] = K2 (time average of every chunk + peak picking), ms[2] = K3, ms[3] = K1 launches per
  * pass, ms[4] = wall time of one pass (first launch to last kernel end), all in milliseconds. */
 int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
