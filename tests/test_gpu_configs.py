@@ -65,11 +65,17 @@ def test_config3_8192_segments_x_10_signals(env):
     h = w.BatchDecoder(nseg // 2, 32)
     h.decode(I[: nseg // 2].contiguous(), Q[: nseg // 2].contiguous())
     assert [[_tup(x) for x in h.spots(s)] for s in range(nseg // 2)] == full[: nseg // 2]
-    # exact agreement with the CPU oracle on 16 sampled segments (all fields of all spots, in order)
-    for s in range(5, nseg, nseg // 16):
-        ref, _, _ = ol.decode(I[s].cpu().numpy(), Q[s].cpu().numpy(), NS)
+    # exact agreement with the CPU oracle on 16 sampled segments (all fields of all spots, in order); a longer
+    # soak: WSPR_CONFIG3_ORACLE_SEGMENTS=512 (the oracle calls run on a thread pool: ctypes drops the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "16"))
+    picks = list(range(5, nseg, nseg // nsample))
+    Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        refs = list(pool.map(lambda s: ol.decode(Ih[s], Qh[s], NS)[0], picks))
+    for s, ref in zip(picks, refs):
         assert _same_as_oracle(dec.spots(s), ref), s
-        assert len(ref) >= 8
+        assert len(ref) >= 8 or nsample > 16
     # neither the Fano budget split of the host pool nor the device search for every attempt (what such a
     # crowded batch runs by default once a pipeline has seen its time-outs) ever changes a result
     L = w.lib()
