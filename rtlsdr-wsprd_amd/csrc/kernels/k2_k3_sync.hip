@@ -407,14 +407,19 @@ void coarse_sync_kernel(const float* __restrict__ ps, const int* __restrict__ se
 // rows: 15.7 KB per wave, ten waves per CU instead of five with whole rows).
 constexpr int kCsChunkSyms = 81;                                 // the fan-out symbol 81 opens the second half
 constexpr int kCsChunkCols = 196;                                // 2 x 80 + 32 lags, widened to whole 16-byte words
-constexpr int kCsChunkWords = 10 * (kCsChunkCols / 4);           // 490 16-byte words per candidate and half
-constexpr int kCsChunkLoads = (2 * kCsChunkWords + 63) / 64;     // 16 per lane
+// The ten staged rows are kept as FIVE rows of pairs (bins if0 - 5 + 2 i and + 2 i + 1 side by side): the sums below
+// work on exactly these pairs, so one 8-byte LDS read delivers a packed operand in one register pair (with ten rows of
+// floats the compiler read ten words per symbol and moved them together: a quarter of the kernel's vector
+// instructions were moves).  A staging lane owns two time columns of one pair row: two 8-byte loads, four square
+// roots, one 16-byte store -- consecutive lanes, consecutive 16-byte words.
+constexpr int kCsPairWords = 5 * (kCsChunkCols / 2);             // 490 16-byte words per candidate and half
+constexpr int kCsChunkLoads = (2 * kCsPairWords + 63) / 64;      // 16 per lane
 static_assert(kNSymD == 2 * kCsChunkSyms, "two halves of 81 symbols");
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void coarse_sync_lane_kernel(const float* __restrict__ ps, const int* __restrict__ seg_list,
                              DevCand* __restrict__ cand, const int* __restrict__ npk, int maxdrift, const SyncBits pr3) {
-    __shared__ __attribute__((aligned(16))) float amp[2][10 * kCsChunkCols];
+    __shared__ __attribute__((aligned(16))) cs2 amp[2][5 * kCsChunkCols];     // [candidate of the wave][pair row][time]
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int blocks = kMaxBlocks;
     const int lane = threadIdx.x, half = lane >> 5, k0 = (lane & 31) - 10;
@@ -437,32 +442,35 @@ void coarse_sync_lane_kernel(const float* __restrict__ ps, const int* __restrict
         const float* __restrict__ src_b = P + (size_t)(if0_b - 5 - kPsBin0) * kPsTPitch;
         // half h covers columns t0 .. t0 + 195 with t0 = -12 (lags down to -10) or 152
         auto stage = [&](int t0) {
-            constexpr int kRound = 8;                            // loads in flight per lane
+            constexpr int kRound = 8;                            // words in flight per lane
             static_assert(kCsChunkLoads % kRound == 0, "whole rounds");
+            typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
             for (int u0 = 0; u0 < kCsChunkLoads; u0 += kRound) {
-                f4 pre[kRound];
+                f2 lo[kRound], hi[kRound];                       // two time columns of the even and of the odd row of a pair
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
-                    const int e = min(lane + 64 * (u0 + u), 2 * kCsChunkWords - 1);
-                    const int cb = e >= kCsChunkWords, el = e - cb * kCsChunkWords, q = el / (kCsChunkCols / 4), w = el - q * (kCsChunkCols / 4);
-                    const int t = t0 + 4 * w;
-                    const float* __restrict__ row = (cb ? src_b : src_a) + (size_t)q * kPsTPitch;
-                    // a negative time index reads the previous bin's row, 347 + index (Q2): t = -12, -8, -4 of the first half
+                    const int e = min(lane + 64 * (u0 + u), 2 * kCsPairWords - 1);
+                    const int cb = e >= kCsPairWords, el = e - cb * kCsPairWords, i = el / (kCsChunkCols / 2), w = el - i * (kCsChunkCols / 2);
+                    const int t = t0 + 2 * w;
+                    const float* __restrict__ row = (cb ? src_b : src_a) + (size_t)(2 * i) * kPsTPitch;
+                    // a negative time index reads the previous bin's row, 347 + index (Q2): t = -12 .. -2 of the first half
                     const float* __restrict__ from = (t >= 0) ? row + t : row - kPsTPitch + blocks + t;
                     if (t >= 0) {
-                        pre[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(from));
+                        lo[u] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(from));
+                        hi[u] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(from + kPsTPitch));
                     } else {
-                        pre[u].x = from[0]; pre[u].y = from[1]; pre[u].z = from[2]; pre[u].w = from[3];
+                        lo[u].x = from[0]; lo[u].y = from[1];
+                        hi[u].x = from[kPsTPitch]; hi[u].y = from[kPsTPitch + 1];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
                     const int e = lane + 64 * (u0 + u);
-                    if (e < 2 * kCsChunkWords) {
-                        f4 r;
-                        r.x = sqrtf(pre[u].x); r.y = sqrtf(pre[u].y); r.z = sqrtf(pre[u].z); r.w = sqrtf(pre[u].w);
-                        *reinterpret_cast<f4*>(&amp[0][0] + 4 * e) = r;       // amp[1] follows amp[0]
+                    if (e < 2 * kCsPairWords) {
+                        f4 r;                                     // (even row, odd row) at t, then at t + 1
+                        r.x = sqrtf(lo[u].x); r.y = sqrtf(hi[u].x); r.z = sqrtf(lo[u].y); r.w = sqrtf(hi[u].y);
+                        *reinterpret_cast<f4*>(&amp[0][0] + 2 * e) = r;       // amp[1] follows amp[0]
                     }
                 }
             }
@@ -485,10 +493,10 @@ void coarse_sync_lane_kernel(const float* __restrict__ ps, const int* __restrict
         stage(-12);
         __syncthreads();
         {
-            const float* __restrict__ A = amp[half] + (k0 + 12);
+            const cs2* __restrict__ A = amp[half] + (k0 + 12);
             auto load = [&](int kk, float (&a)[10]) {
 #pragma unroll
-                for (int q = 0; q < 10; ++q) a[q] = A[q * kCsChunkCols + 2 * kk];
+                for (int i = 0; i < 5; ++i) { const cs2 v = A[i * kCsChunkCols + 2 * kk]; a[2 * i] = v.x; a[2 * i + 1] = v.y; }
             };
             float a0[10], a1[10];
             load(0, a0);
@@ -511,10 +519,10 @@ void coarse_sync_lane_kernel(const float* __restrict__ ps, const int* __restrict
         stage(152);
         __syncthreads();
         {
-            const float* __restrict__ A = amp[half] + (k0 + 2 * kCsChunkSyms - 152);
+            const cs2* __restrict__ A = amp[half] + (k0 + 2 * kCsChunkSyms - 152);
             auto load = [&](int kk, float (&a)[10]) {            // kk = symbol - 81
 #pragma unroll
-                for (int q = 0; q < 10; ++q) a[q] = A[q * kCsChunkCols + 2 * kk];
+                for (int i = 0; i < 5; ++i) { const cs2 v = A[i * kCsChunkCols + 2 * kk]; a[2 * i] = v.x; a[2 * i + 1] = v.y; }
             };
             auto drifting = [&](const float (&a)[10]) {          // after bins(k, a): m01 / m23 are this symbol's
                 const cs2 A0 = {a[0], a[1]}, A1 = {a[2], a[3]}, A2 = {a[4], a[5]}, A3 = {a[6], a[7]}, A4 = {a[8], a[9]};
