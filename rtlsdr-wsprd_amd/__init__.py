@@ -231,5 +231,5 @@ def last_timings():
     n = lib().wspr_last_timings(C.addressof(ms), 16)
     names = ["fft_sync_ms", "host_bookkeeping_ms", "device_fano_tail_ms", "demod_ms", "subtract_ms", "host_fano_ms",
              "total_ms", "fano_calls", "fano_timeouts", "fano_cycles", "candidates_refined", "gpu_waves",
-             "fano_left_to_device", "segments_redecoded"]
+             "fano_left_to_device", "segments_redecoded", "candidates_consumed", "subtractions"]
     return {names[i]: ms[i] for i in range(n)}

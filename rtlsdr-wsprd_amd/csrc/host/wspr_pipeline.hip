@@ -170,7 +170,7 @@ struct Context::Impl {
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
     double t_ms[16] = {0};           // stage times (ms) and Fano statistics of the last batch
-    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0};
+    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0};
     bool blocking = false;
     hipEvent_t ev_sync = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -577,7 +577,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                              wspr_trace* trace) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
-    c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0;
+    c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     for (int s = 0; s < nseg; ++s) n_results[s] = 0;
     const int blocks = 4 * (samples / kFftSize) - 1;
@@ -628,6 +628,8 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     c.t_ms[7] = (double)c.n_fano.load();
     c.t_ms[8] = (double)c.n_timeout.load();
     c.t_ms[9] = (double)c.n_cycles.load();
+    c.t_ms[14] = (double)c.n_kept.load();                 // refined candidates whose result was consumed (the rest: cut speculation)
+    c.t_ms[15] = (double)c.n_subjobs.load();
     c.crowded = c.n_timeout.load() * 10 > nseg;
     return 0;
 }
@@ -1129,6 +1131,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         WaveItem& w = wave[i];
         const int s = w.seg;
         if (stopped[s]) break;
+        c.n_kept++;
         if (lockstep) next_cand[s] = w.cand + 1;
         DevCand& cd = cand[(size_t)s * kMaxCand + w.cand];
         cd.freq = w.fine.freq; cd.shift = w.fine.shift; cd.drift = w.fine.drift; cd.sync = w.fine.sync;
@@ -1201,6 +1204,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
     });
     std::vector<SubJob> jobs;
     for (int i = 0; i < nw; ++i) if (has_job[i]) jobs.push_back(job_of[i]);
+    c.n_subjobs += (long)jobs.size();
     c.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b0).count();
     return jobs;
 }
@@ -1302,7 +1306,7 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 14);
+    const int n = std::min(cap, 16);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }

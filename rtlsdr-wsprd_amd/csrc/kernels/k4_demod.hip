@@ -627,6 +627,228 @@ void demod_lag3_kernel(const float* __restrict__ dI, const float* __restrict__ d
         pw_out[((size_t)item * nlag + m) * kNSymD + 3 * q + r] = acc[r].amplitudes();
 }
 
+// -----------------------------------------------------------------------------
+// Lag scan (mode 0: 33 lags, step 8) of a DRIFT-FREE candidate as ONE strided correlation, samples in registers.
+//
+// With one table for the whole frame the accumulator of (symbol s, lag m) is
+//     A[u] = sum_j x[k0 + 8 u + j] * tab[j],   u = 32 s + m,   k0 = shift_coarse - 128
+// (wsprd.c:190-207: k = lag + 256 s + j with lag = k0 + 8 m): a 256-tap correlation of the sample stream evaluated
+// every 8 samples.  Two consequences:
+//   * (s, 32) and (s + 1, 0) are the SAME sum over the same samples in the same order, so only u = 0 .. 5184 are
+//     distinct (5 185 sums instead of 33 x 162 = 5 346) and the lag-32 row of the output is a copy;
+//   * output u + 1 at step j reads the sample output u reads at step j + 8.  A lane that owns ROWS consecutive
+//     outputs keeps their current 8-sample vectors in registers; after 8 steps row r takes over row r + 1's
+//     vector (a register renaming: the loop is unrolled over ROWS + 1 blocks), and the last row takes the first
+//     row of the NEXT lane with one DPP move per register (v_mov_b32_dpp wave_shl:1).  Lane 63's successor lies
+//     outside the wave: its vector (8 new samples per 8 steps for the whole wave) is loaded from memory a block
+//     ahead by every lane at the same address and enters through the DPP move's "old" operand.
+// No LDS and no barrier: a wave is its own workgroup, occupancy is set by registers alone (the tiled kernel's 57 KB
+// of samples per 256 lanes held it at two waves per SIMD), and the hot loop has no memory instruction that a lane
+// waits for except the table's scalar loads (27 waves of a candidate share the table: scalar-cache hits).
+// Per 8 steps and lane: 8 x 16 x ROWS packed multiplies/adds, 16 DPP moves, 16 uniform loads.
+// u = 5184 (symbol 161 at lag 32) has no lane: one extra workgroup per 64 candidates sums it, a candidate per lane.
+// Same operations per accumulator as demod_kernel => identical bits.
+#ifndef LAGSYS_EXP
+#define LAGSYS_EXP 0
+#endif
+constexpr int kSysRows = 3;
+constexpr int kSysU = 64 * kSysRows;                        // outputs per wave
+constexpr int kSysOutputs = 32 * kNSymD;                    // u = 0 .. 5183 (+ u = 5184: the extra)
+constexpr int kSysWaves = kSysOutputs / kSysU;              // 27
+static_assert(kSysOutputs % kSysU == 0, "waves cover the outputs exactly");
+
+// wsprd.c:199: a sample outside 0 < k < np is skipped; adding x*c with x = 0 leaves the sums as they are
+__device__ __forceinline__ float sys_load_checked(const float* __restrict__ x, int k, int np) {
+    const float v = x[min(max(k, 0), np - 1)];
+    return (k > 0 && k < np) ? v : 0.0f;
+}
+
+// lane l takes src of lane l + 1; lane 63 keeps old (v_mov_b32_dpp wave_shl:1; tools/dpp_probe.hip).  The operands are
+// float PARAMETERS on purpose: __builtin_bit_cast applied to a vector element (F.y) reads element 0 with this clang.
+__device__ __forceinline__ float wave_shl1(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 0x130, 0xf, 0xf, false));
+}
+
+// the whole wave lies inside the record: no bounds tests anywhere
+__device__ __forceinline__ void lagsys_wave(const float* __restrict__ xi, const float* __restrict__ xq, int kw,
+                                            const float4* __restrict__ gtab, ToneAcc (&acc)[kSysRows]) {
+    constexpr int R = kSysRows, NS = R + 1;
+    const int lane = threadIdx.x;
+    // slot = one 8-sample vector: [0..3] pairs of I, [4..7] pairs of Q
+    v2f S[NS][8];
+    {
+        const float* __restrict__ pi = xi + kw + 8 * R * lane;
+        const float* __restrict__ pq = xq + kw + 8 * R * lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                S[r][i] = (v2f){pi[8 * r + 2 * i], pi[8 * r + 2 * i + 1]};
+                S[r][4 + i] = (v2f){pq[8 * r + 2 * i], pq[8 * r + 2 * i + 1]};
+            }
+    }
+    // lane 63's successor: the same address in every lane, but as VECTOR loads (the value must arrive in a VGPR, and
+    // scalar loads would queue behind the table's): the zero the compiler cannot see through keeps them per-lane
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    const float* __restrict__ fi = xi + kw + 8 * R * 64 + zero;
+    const float* __restrict__ fq = xq + kw + 8 * R * 64 + zero;
+    auto fresh = [&](v2f (&F)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            F[i] = (v2f){fi[2 * i], fi[2 * i + 1]};
+            F[4 + i] = (v2f){fq[2 * i], fq[2 * i + 1]};
+        }
+        fi += 8;
+        fq += 8;
+    };
+    fresh(S[R]);
+    struct Stage { float4 c[2], s[2]; };
+    auto issue = [&](Stage& g, int j) {                      // j even; clamped past the end (values unused)
+        const int jj = j < kSps ? j : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { g.c[u] = gtab[2 * (jj + u)]; g.s[u] = gtab[2 * (jj + u) + 1]; }
+    };
+    Stage A, B;
+    issue(A, 0);
+#pragma unroll 1
+    for (int b0 = 0; b0 < kSps / 8; b0 += NS) {
+#pragma unroll
+        for (int bb = 0; bb < NS; ++bb) {
+            // rows of this block: slots (bb + r) % NS; the slot behind them receives the next vector of lane 63
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                    // a stage = steps 2q, 2q + 1 of the block
+                Stage& cur = (q & 1) ? B : A;
+                Stage& nxt = (q & 1) ? A : B;
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this stage's table entries have landed
+                __builtin_amdgcn_sched_barrier(0);
+                issue(nxt, 8 * (b0 + bb) + 2 * q + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 c4 = cur.c[u], s4 = cur.s[u];
+                    const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+                    v2f p[R][8];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const v2f iv = S[(bb + r) % NS][q], qv = S[(bb + r) % NS][4 + q];
+                        const float x = u ? iv.y : iv.x, y = u ? qv.y : qv.x;
+                        const v2f xx = {x, x}, yy = {y, y};
+                        p[r][0] = xx * c01; p[r][1] = xx * c23; p[r][2] = xx * s01; p[r][3] = xx * s23;
+                        p[r][4] = yy * s01; p[r][5] = yy * s23; p[r][6] = yy * c01; p[r][7] = yy * c23;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {           // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
+                        acc[r].i01 = acc[r].i01 + p[r][0]; acc[r].i23 = acc[r].i23 + p[r][1];
+                        acc[r].q01 = acc[r].q01 - p[r][2]; acc[r].q23 = acc[r].q23 - p[r][3];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r].i01 = acc[r].i01 + p[r][4]; acc[r].i23 = acc[r].i23 + p[r][5];
+                        acc[r].q01 = acc[r].q01 + p[r][6]; acc[r].q23 = acc[r].q23 + p[r][7];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // hand-over: the slot that held the first row now belongs to nobody; the last row of the next block is
+            // the first row of the next lane (lane 63: the vector loaded a block ago)
+            v2f (&F)[8] = S[(bb + R) % NS];
+            const v2f (&G)[8] = S[bb % NS];
+#pragma unroll
+#if !(LAGSYS_EXP & 1)
+            for (int i = 0; i < 8; ++i) {
+                F[i].x = wave_shl1(F[i].x, G[i].x);
+                F[i].y = wave_shl1(F[i].y, G[i].y);
+            }
+#endif
+#if !(LAGSYS_EXP & 2)
+            fresh(S[bb % NS]);                               // wanted one block from now
+#endif
+        }
+    }
+}
+
+__device__ __forceinline__ void lagsys_store(const ToneAcc (&acc)[kSysRows], int u0, size_t item, float4* __restrict__ pw_out) {
+    constexpr int nlag = 33;
+#pragma unroll
+    for (int r = 0; r < kSysRows; ++r) {
+        const int u = u0 + kSysRows * (int)threadIdx.x + r, sym = u >> 5, m = u & 31;
+        const float4 a = acc[r].amplitudes();
+        pw_out[(item * nlag + m) * kNSymD + sym] = a;
+        if (m == 0 && sym > 0) pw_out[(item * nlag + 32) * kNSymD + sym - 1] = a;     // (s - 1, lag 32) == (s, lag 0)
+    }
+}
+
+// a wave that hangs over either end of the record (the first wave of an early candidate): every lane walks its
+// outputs sample by sample with the reference's bounds test
+__device__ __noinline__ void lagsys_edge_wave(const float* __restrict__ xi, const float* __restrict__ xq, int np, int kw,
+                                              const float4* __restrict__ gtab, int u0, size_t item,
+                                              float4* __restrict__ pw_out) {
+    ToneAcc acc[kSysRows];
+#pragma unroll
+    for (int r = 0; r < kSysRows; ++r) acc[r].clear();
+    const int kl = kw + 8 * kSysRows * (int)threadIdx.x;
+#pragma unroll 1
+    for (int j = 0; j < kSps; ++j) {
+        const float4 c4 = gtab[2 * j], s4 = gtab[2 * j + 1];
+#pragma unroll
+        for (int r = 0; r < kSysRows; ++r) {
+            const int k = kl + 8 * r + j;
+            acc[r].step(make_float2(sys_load_checked(xi, k, np), sys_load_checked(xq, k, np)), c4, s4);
+        }
+    }
+    lagsys_store(acc, u0, item, pw_out);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                         const FineState* __restrict__ items, const int* __restrict__ item_list, int nitems,
+                         const float* __restrict__ tabs, float4* __restrict__ pw_out) {
+    constexpr int nlag = 33;
+    const int lane = threadIdx.x;
+    if (blockIdx.x == kSysWaves) {
+#if (LAGSYS_EXP & 4)
+        return;
+#endif
+        // u = 5184: (symbol 161, lag 32) of 64 candidates, one per lane
+        if (blockIdx.y & 63) return;
+        const int pos = blockIdx.y + lane;
+        if (pos >= nitems) return;
+        const int item = item_list[pos];
+        const FineState st = items[item];
+        const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+        const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+        const float4* __restrict__ tb = reinterpret_cast<const float4*>(tabs) + (size_t)st.pad * 512;
+        const int k0 = st.shift_coarse - 128 + 8 * kSysOutputs;
+        ToneAcc a;
+        a.clear();
+#pragma unroll 2
+        for (int j = 0; j < kSps; ++j)
+            a.step(make_float2(sys_load_checked(xi, k0 + j, np), sys_load_checked(xq, k0 + j, np)), tb[2 * j], tb[2 * j + 1]);
+        pw_out[((size_t)item * nlag + 32) * kNSymD + kNSymD - 1] = a.amplitudes();
+        return;
+    }
+    const int item = item_list[blockIdx.y];
+    const FineState st = items[item];
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const int u0 = blockIdx.x * kSysU;
+    const int kw = __builtin_amdgcn_readfirstlane(st.shift_coarse - 128 + 8 * u0);
+    const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
+                                      (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
+    // samples the wave touches: kw .. kw + 8 * 192 + 8 * 31 + 7 (one more vector is fetched and never used)
+    if (kw > 0 && kw + 8 * kSysU + kSps + 8 <= np) {
+        ToneAcc acc[kSysRows];
+#pragma unroll
+        for (int r = 0; r < kSysRows; ++r) acc[r].clear();
+        lagsys_wave(xi, xq, kw, gtab, acc);
+        lagsys_store(acc, u0, (size_t)item, pw_out);
+    } else {
+        lagsys_edge_wave(xi, xq, np, kw, gtab, u0, (size_t)item, pw_out);
+    }
+}
+
 // folds the 162 per-symbol tone amplitudes of one (candidate, lag) in symbol order
 __global__ __launch_bounds__(64)
 void demod_metric_kernel(const float4* __restrict__ pw, const FineState* __restrict__ items, int nitems,
@@ -1047,13 +1269,18 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     float4* pw4 = reinterpret_cast<float4*>(pw);
     // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one symbol per lane)
     static const bool lag3_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
+    // WSPR_K4_LAG=lag3: the LDS-tiled three-symbols-per-lane kernel instead of the register-resident correlation
+    static const bool lagsys_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !e || !e[0] || e[0] == 's'; }();
     static std::atomic<unsigned> l3_opted{0};
     if (lag3_kernel) lds_opt_in(reinterpret_cast<const void*>(&demod_lag3_kernel), 8 * kL3Pitch * sizeof(float2), l3_opted);
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
     static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
-        if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lag3_kernel)                                 \
+        if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
+            hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves + 1, n_shared), dim3(64), 0, st, dI, dQ,      \
+                               samples, items, list_shared, n_shared, tabs, pw4);                                \
+        else if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lag3_kernel)                            \
             hipLaunchKernelGGL(demod_lag3_kernel, dim3(kL3Wgs, n_shared), dim3(kL3Threads),                      \
                                (size_t)8 * kL3Pitch * sizeof(float2), st, dI, dQ, samples, items, list_shared,   \
                                tabs, pw4);                                                                       \

@@ -237,70 +237,83 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
         }
     }
     __syncthreads();
-    // outputs n0 + 8 tid + r, r = 0..7; input of tap j for output r: e = 8 tid + r + j
-    v2f acc[8], x[8];
+    // the last tile reaches past the end of the signal: a wave without outputs has nothing to filter
+    if (n0 + 8 * (tid & ~63) >= kSigLen) return;
+    // outputs n0 + 8 tid + r, r = 0..7; input of tap j for output r: e = 8 tid + r + j.
+    // The eight-sample window lives in THREE register sets that take turns (no register is ever copied): during
+    // stage k (taps 8k .. 8k + 7) set k % 3 holds the window as the stage found it, set (k + 1) % 3 the eight
+    // samples that enter under these taps (at tap u the window is in[0..u-1] | old[u..7]), and set (k + 2) % 3
+    // receives the samples of stage k + 1, issued before stage k is consumed.
+    v2f acc[8], W[3][8];
+    float4 Ta[3], Tb[3];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         acc[r] = (v2f){0.0f, 0.0f};
         const float2 t = tile[r * kFir8Pitch + tid];
-        x[r] = (v2f){t.x, t.y};
+        W[0][r] = (v2f){t.x, t.y};
     }
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(lpf);
-    struct Stage { float4 wa, wb; float2 in[8]; };
-    auto issue = [&](Stage& g, int j) {                      // taps j..j+7 and the samples that enter the window under them
-        const int jj = j < kLpfTaps ? j : 0;
-        g.wa = w4[jj / 4];
-        g.wb = w4[jj / 4 + 1];
+    auto issue = [&](v2f (&in)[8], float4& wa, float4& wb, int k) {   // taps 8k .. 8k + 7 and the samples that enter under them
+        const int kk = 8 * k < kLpfTaps ? k : 0;             // clamped past the end (values unused)
+        wa = w4[2 * kk];
+        wb = w4[2 * kk + 1];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) g.in[u] = tile[u * kFir8Pitch + tid + 1 + (jj >> 3)];
+        for (int u = 0; u < 8; ++u) {
+            const float2 t = tile[u * kFir8Pitch + tid + 1 + kk];
+            in[u] = (v2f){t.x, t.y};
+        }
     };
-    auto consume = [&](const Stage& g) {
-        const float w[8] = {g.wa.x, g.wa.y, g.wa.z, g.wa.w, g.wb.x, g.wb.y, g.wb.z, g.wb.w};
+    auto consume = [&](const v2f (&old)[8], const v2f (&in)[8], const float4 wa, const float4 wb) {
+        const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const v2f wu = {w[u], w[u]};
             v2f p[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) p[r] = wu * x[(u + r) & 7];
+            for (int r = 0; r < 8; ++r) {
+                const int i = (u + r) & 7;
+                p[r] = wu * (i < u ? in[i] : old[i]);
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = acc[r] + p[r];
-            x[u & 7] = (v2f){g.in[u].x, g.in[u].y};
         }
     };
-    Stage A, B;
-    issue(A, 0);
+    issue(W[1], Ta[0], Tb[0], 0);
+    static_assert(kLpfTaps % 24 == 0, "three stages of eight taps per trip");
 #pragma unroll 1
-    for (int j = 0; j < kLpfTaps; j += 16) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): stage A has landed
-        __builtin_amdgcn_sched_barrier(0);
-        issue(B, j + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(A);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 8 < kLpfTaps) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int k0 = 0; k0 < kLpfTaps / 8; k0 += 3) {
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this stage's taps and samples have landed
             __builtin_amdgcn_sched_barrier(0);
-            issue(A, j + 16);
+            issue(W[(s3 + 2) % 3], Ta[(s3 + 1) % 3], Tb[(s3 + 1) % 3], k0 + s3 + 1);
             __builtin_amdgcn_sched_barrier(0);
-            consume(B);
+            consume(W[s3], W[(s3 + 1) % 3], Ta[s3], Tb[s3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // wsprd.c:397-404: only the first and last 180 outputs of the signal are normalised by a partial tap sum; for
+    // all the others norm == 1 and x / 1.0f == x exactly, so interior tiles do not divide
+    const bool edge_tile = n0 < kLpfTaps / 2 || n0 + kFir8Out > kSigLen - kLpfTaps / 2;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = n0 + 8 * tid + r;
         if (n >= kSigLen) break;
-        float norm = 1.0f;                                   // wsprd.c:397-404
-        if (n < kLpfTaps / 2)                    norm = lpf_part[kLpfTaps / 2 + n];
-        else if (n > kSigLen - 1 - kLpfTaps / 2) norm = lpf_part[kLpfTaps / 2 + kSigLen - 1 - n];
         const int k = shift + n;
         if (k > 0 && k < np) {
             const float2 rr = rref[8 * tid + r];
             const float si = acc[r].x, sq = acc[r].y;
             const float a = si * rr.x, b = sq * rr.y, c = si * rr.y, d = sq * rr.x;
-            const float ri = a - b, rq = c + d;
-            xi[k] = xi[k] - ri / norm;
-            xq[k] = xq[k] - rq / norm;
+            float ri = a - b, rq = c + d;
+            if (edge_tile) {
+                float norm = 1.0f;
+                if (n < kLpfTaps / 2)                    norm = lpf_part[kLpfTaps / 2 + n];
+                else if (n > kSigLen - 1 - kLpfTaps / 2) norm = lpf_part[kLpfTaps / 2 + kSigLen - 1 - n];
+                ri = ri / norm;
+                rq = rq / norm;
+            }
+            xi[k] = xi[k] - ri;
+            xq[k] = xq[k] - rq;
         }
     }
 }
