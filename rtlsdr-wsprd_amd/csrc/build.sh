@@ -8,7 +8,7 @@ trap "echo BUILD FAILED >&2" ERR
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libwspr_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result ${WSPR_EXTRA_FLAGS:-}"
 mkdir -p "$here/obj"
 srcs=(kernels/k0_decimate.hip kernels/k1_fft_bank.hip kernels/k2_k3_sync.hip kernels/k4_demod.hip
       kernels/k6_fano_wave.hip kernels/k7_subtract.hip host/wspr_pipeline.hip host/wspr_capi.hip)

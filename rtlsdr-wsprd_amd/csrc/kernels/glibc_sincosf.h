@@ -139,29 +139,56 @@ WSPR_HD float glibc_sincosf(float y, int which) {
 
 // sinf(y) and cosf(y) with ONE shared argument reduction (the two libm calls reduce the
 // same argument identically, so sharing it changes nothing but the cost)
+// Both polynomials of one reduced argument, signs left out: sincos_poly() is odd in x on its sine branch (x enters every
+// term once) and its cosine branch only multiplies every coefficient by sg = +-1, and round-to-nearest is symmetric, so
+//   sincos_poly(x * s, x2, neg, even n) == s * S   and   sincos_poly(x * s, x2, neg, odd n) == (neg ? -C : C)
+// bit for bit, with S and C evaluated once for +x and sg = +1.  (A lane-dependent n made a wavefront walk both branches
+// for the sine AND for the cosine: four polynomials per sample where two are enough.)
+WSPR_HD void sincos_both(double x, double x2, float* S, float* Cc) {
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
+    const double x3 = x * x2;
+    const double t  = mad(x2, s3, s2);
+    const double x7 = x3 * x2;
+    const double s  = mad(x3, s1, x);
+    *S = (float)mad(x7, t, s);
+    const double x4 = x2 * x2;
+    const double t2 = mad(x2, c4, c3);
+    const double t1 = mad(x2, c1, c0);
+    const double x6 = x4 * x2;
+    const double c  = mad(x4, c2, t1);
+    *Cc = (float)mad(x6, t2, c);
+}
+
+// quadrant n (and the reference's sign bookkeeping) applied to the two polynomial values
+WSPR_HD void sincos_place(float S, float Cc, int n, int nsign, float* sn, float* cs) {
+    const int q = nsign & 3;
+    const float sp = (q == 1 || q == 2) ? -S : S;              // sign table {1,-1,-1,1} on the sine branch
+    const float cp = (nsign & 2) ? -Cc : Cc;                   // sg on the cosine branch
+    const bool odd = (n & 1) != 0;
+    *sn = odd ? cp : sp;
+    *cs = odd ? sp : cp;
+}
+
 WSPR_HD void glibc_sincosf_pair(float y, float* sn, float* cs) {
     double x = y;
     int n;
     if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
         if (abstop12(y) < abstop12(0x1p-12f)) { *sn = y; *cs = 1.0f; return; }
-        const double x2 = x * x;
-        *sn = sincos_poly(x, x2, false, 0);
-        *cs = sincos_poly(x, x2, false, 1);
+        sincos_both(x, x * x, sn, cs);
     } else if (abstop12(y) < abstop12(120.0f)) {
         x = reduce_small(x, &n);
-        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-        const double xs = x * s, x2 = x * x;
-        *sn = sincos_poly(xs, x2, (n & 2) != 0, n);
-        *cs = sincos_poly(xs, x2, (n & 2) != 0, n ^ 1);
+        float S, Cc;
+        sincos_both(x, x * x, &S, &Cc);
+        sincos_place(S, Cc, n, n, sn, cs);
     } else if (abstop12(y) < 0x7f8) {
         const uint32_t xi = f32_bits(y);
         const int sign = (int)(xi >> 31);
         x = reduce_big(xi, &n);
-        const int q = (n + sign) & 3;
-        const double s = (q == 1 || q == 2) ? -1.0 : 1.0;
-        const double xs = x * s, x2 = x * x;
-        *sn = sincos_poly(xs, x2, ((n + sign) & 2) != 0, n);
-        *cs = sincos_poly(xs, x2, ((n + sign) & 2) != 0, n ^ 1);
+        float S, Cc;
+        sincos_both(x, x * x, &S, &Cc);
+        sincos_place(S, Cc, n, n + sign, sn, cs);
     } else {
         *sn = *cs = y - y;
     }

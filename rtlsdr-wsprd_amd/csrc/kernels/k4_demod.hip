@@ -729,24 +729,17 @@ __device__ __forceinline__ void lagsys_wave(const float* __restrict__ xi, const 
                 for (int u = 0; u < 2; ++u) {
                     const float4 c4 = cur.c[u], s4 = cur.s[u];
                     const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
-                    v2f p[R][8];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
+                    for (int r = 0; r < R; ++r) {           // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
                         const v2f iv = S[(bb + r) % NS][q], qv = S[(bb + r) % NS][4 + q];
                         const float x = u ? iv.y : iv.x, y = u ? qv.y : qv.x;
                         const v2f xx = {x, x}, yy = {y, y};
-                        p[r][0] = xx * c01; p[r][1] = xx * c23; p[r][2] = xx * s01; p[r][3] = xx * s23;
-                        p[r][4] = yy * s01; p[r][5] = yy * s23; p[r][6] = yy * c01; p[r][7] = yy * c23;
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {           // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
-                        acc[r].i01 = acc[r].i01 + p[r][0]; acc[r].i23 = acc[r].i23 + p[r][1];
-                        acc[r].q01 = acc[r].q01 - p[r][2]; acc[r].q23 = acc[r].q23 - p[r][3];
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        acc[r].i01 = acc[r].i01 + p[r][4]; acc[r].i23 = acc[r].i23 + p[r][5];
-                        acc[r].q01 = acc[r].q01 + p[r][6]; acc[r].q23 = acc[r].q23 + p[r][7];
+                        const v2f p0 = xx * c01, p1 = xx * c23, p2 = xx * s01, p3 = xx * s23;
+                        const v2f p4 = yy * s01, p5 = yy * s23, p6 = yy * c01, p7 = yy * c23;
+                        acc[r].i01 = acc[r].i01 + p0; acc[r].i23 = acc[r].i23 + p1;
+                        acc[r].q01 = acc[r].q01 - p2; acc[r].q23 = acc[r].q23 - p3;
+                        acc[r].i01 = acc[r].i01 + p4; acc[r].i23 = acc[r].i23 + p5;
+                        acc[r].q01 = acc[r].q01 + p6; acc[r].q23 = acc[r].q23 + p7;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -801,7 +794,10 @@ __device__ __noinline__ void lagsys_edge_wave(const float* __restrict__ xi, cons
     lagsys_store(acc, u0, item, pw_out);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef LAGSYS_WAVES
+#define LAGSYS_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LAGSYS_WAVES, LAGSYS_WAVES)))
 void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                          const FineState* __restrict__ items, const int* __restrict__ item_list, int nitems,
                          const float* __restrict__ tabs, float4* __restrict__ pw_out) {
