@@ -286,6 +286,64 @@ def k0_report(L, m, with_cpu=True):
     return out
 
 
+def reference_case_block(with_cpu):
+    """BASELINE configs[0] / the reference's only published metric (README.md:138-151: the decode burst per 2-minute
+    segment, 0.5 s on an i7-5820K): ONE wspr_decode() call on the reference's own signal file through the host-buffer
+    entry point -- H2D, decode, residual and spots back -- as rtlsdr_wsprd.c:316 calls it once every 120 s."""
+    import oracle_lib as ol
+    I, Q, n = ol.read_iq_file(os.path.join(ROOT, "tests", "golden", "refSignalSnr0dB.iq"))
+    opt = w.default_options()
+    for _ in range(3):
+        spots, _, _ = w.wspr_decode(I, Q, n, opt)
+    times = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        spots, _, _ = w.wspr_decode(I, Q, n, opt)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    blk = {"workload": "configs[0]: signals/refSignalSnr0dB.iq, one wspr_decode() call (host buffers in, residual and "
+                       "spots out), warm, median of 20",
+           "ms_per_call": 1e3 * times[len(times) // 2], "ms_min": 1e3 * times[0], "ms_max": 1e3 * times[-1],
+           "spots": [ol.spot_line(x) for x in spots],
+           "published_reference": {"ms_per_call": 500.0, "hardware": "i7-5820K, one core, FFTW (reference README.md:138-151)",
+                                   "note": "context only: other hardware, never a vs_baseline"}}
+    if with_cpu:
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ref, _, _ = ol.decode(I, Q, n)
+        blk["cpu_oracle_one_core_ms_per_call"] = 1e3 * (time.perf_counter() - t0) / 5
+        blk["equal_to_oracle"] = [ol.spot_line(x) for x in ref] == blk["spots"]
+    return blk
+
+
+def share_of_8_block(args, inflight):
+    """What ONE rank of an 8-rank job on this host gets: configs[2] again in a child process whose library sees 1/8 of
+    the usable CPUs (WSPR_HOST_THREADS), same batches in flight.  A SCALE value at N = 8 can be read against 8 x this
+    figure: below it the curve is limited by something other than the ranks' CPU shares."""
+    share = max(1, usable_cpus() // 8)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["WSPR_HOST_THREADS"] = str(share)
+    env["OMP_NUM_THREADS"] = str(share)
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "3", "--steps", "8", "--warmup", "3", "--no-cpu-baseline",
+           "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case", "--no-ceilings",
+           "--inflight", str(inflight)]
+    if args.segments:
+        cmd += ["--segments", str(args.segments)]
+    import subprocess
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child bench failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+    d = json.loads(lines[-1])
+    return {"workload": d["config"]["workload"], "host_threads": d["host_threads"], "of_usable_cpus": usable_cpus(),
+            "batches_in_flight": d["config"]["batches_in_flight"], "value": d["value"], "unit": "segments/s",
+            "ms_per_step": d["ms_per_step"], "steps": d["steps"], "decoded_ok": d["decoded_ok"],
+            "false_decodes": d["false_decodes"], "host_pool_workers": d.get("host_pool_workers"),
+            "expected_8_gpu_aggregate": 8 * d["value"], "child_wall_s": time.perf_counter() - t0,
+            "note": "same GPU, same kernels; the host side (lane threads, bookkeeping, copies) runs on %d CPU(s)" % share}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: re-executes this script as N ranks of ONE node under
     torch.distributed.run (one rank per GPU, RCCL over xGMI, rendezvous on 127.0.0.1), each rank with its share of
@@ -329,6 +387,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
     ap.add_argument("--no-tertiary", action="store_true", help="skip the configs[4] block of the N=1 line")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the copy / read / write calibration kernels")
+    ap.add_argument("--no-share-block", action="store_true",
+                    help="skip the per_rank_share_of_8 block (configs[2] again in a child process with 1/8 of the CPUs)")
+    ap.add_argument("--no-reference-case", action="store_true", help="skip the configs[0] block (one wspr_decode() call)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 --pmc passes (about 40 s); read it from profiles/")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
@@ -369,6 +431,18 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert w.lib().wspr_device_ready() == 1, "HIP extension / device not usable"
+    # how many physical devices the ranks really sit on (advisor, round 3: with WSPR_BENCH_SHARE_GPU a two-rank line
+    # said n_gpus 2 while one GPU did the work)
+    import socket
+    try:
+        my_dev = (socket.gethostname(), str(torch.cuda.get_device_properties(local).uuid))
+    except Exception:
+        my_dev = (socket.gethostname(), local)
+    devs = [my_dev]
+    if use_dist:
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev)
+    distinct_devices = len(set(devs))
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
     if args.k0_cus is not None:
@@ -559,7 +633,7 @@ def main():
                                "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
                                          pm["calibration"]["true_bytes_per_counted_read_byte"],
                                          pm["calibration"]["true_bytes_per_counted_written_byte"]))
-        for name in (() if traffic else ("r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
+        for name in (() if traffic else ("r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
             tf = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tf):
                 jd = json.load(open(tf))
@@ -597,12 +671,12 @@ def main():
                             "measured_no_fma_TFs": mtf.value,
                             "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
                                     "half the FMA peak",
-                            "K4_lag_scan (demod_lag3_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
+                            "K4_lag_scan (demod_lagsys_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
                             "K4_freq_scan_first_rung (freq_scalar_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
                             "K7_subtract (sub_runs_wave_kernel + sub_fir_fused_kernel)": valu(K7_FLOP, vms[3], vms[1])}
         # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
         # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
-        if args.config != 5:
+        if args.config != 5 and not args.no_ceilings:
             n_copy = 1 << 28
             src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
             dst = torch.empty_like(src)
@@ -667,7 +741,8 @@ def main():
             torch.cuda.empty_cache()
         out = {
             "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
-            "unit": "segments/s", "n_gpus": world, "steps": m["steps"], "warmup": args.warmup,
+            "unit": "segments/s", "n_gpus": world, "distinct_devices": distinct_devices,
+            "devices_shared": distinct_devices < world, "steps": m["steps"], "warmup": args.warmup,
             "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": m["workload"] + ", 45000 complex f32 samples @ 375 sps, resident in HBM; reference "
@@ -683,9 +758,16 @@ def main():
                                                          "step; counts: sum over its slots"),
             "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
+            "host_pool_workers": int(L.wspr_host_pool_workers()),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,
             "fanout_check": fanout,
         }
+        if world == 1 and not use_dist and args.config == 3:
+            if not args.no_reference_case:
+                out["reference_case_configs0"] = reference_case_block(not args.no_cpu_baseline)
+            if not args.no_share_block:
+                torch.cuda.empty_cache()
+                out["per_rank_share_of_8"] = share_of_8_block(args, inflight)
     line = json.dumps(out) if rank == 0 else None
     if use_dist:
         dist.barrier()

@@ -63,8 +63,17 @@ struct decoder_results {            /* 80 bytes: the spot record */
 /* Replaces wspr_decode(), reference wsprd/wsprd.h:106-111 / wsprd/wsprd.c:416.
  * Same contract: idat/qdat (length `samples`, <= 45000) are overwritten with the
  * residual after coherent subtraction, decodes[0..*n_results) is filled strongest
- * first, returns 0 (a negative value, with a message on stderr, only if no HIP device is usable: there
- * is no CPU fallback).  One call = a batch of one segment on the GPU.  With options.usehashtable the
+ * first, returns 0.
+ *
+ * DIFFERENCE FROM THE REFERENCE -- CHECK THE RETURN VALUE.  The reference's wspr_decode() cannot fail and always
+ * returns 0 (wsprd.c:854).  This one returns a NEGATIVE value, with a message on stderr and *n_results = 0, when
+ *   -1  no HIP device is usable or a HIP call failed (there is no CPU fallback), or
+ *   -2  samples > 45000: the reference sizes its FFT bank from `samples` (wsprd.c:516) and would read beyond the
+ *       45 000 samples its callers hold; this library's working rows are 45 000 samples and a longer record is
+ *       refused rather than silently cut (rounds 1-3 cut it).
+ * The same codes come back from every wspr_decode_batch*() entry point.
+ *
+ * One call = a batch of one segment on the GPU.  With options.usehashtable the
  * reference's hashtable.txt side effect is kept (read before, written after the decode, wsprd.c:481-494,
  * 842-852); fftw_wisdom.dat is not (there is no FFTW). */
 int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options options,
@@ -268,9 +277,14 @@ int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int sa
  * streams / host clock, summed over the slots).  Order: [0] FFT+sync stage, [1] host bookkeeping,
  * [2] device Fano tail (K6), [3] fine sync + demod, [4] subtract, [5] host Fano, [6] total wall time,
  * then counts: [7] Fano calls, [8] Fano time-outs, [9] Fano cycles, [10] candidates refined, [11] GPU
- * waves, [12] Fano attempts left to the device tail, [13] segments decoded a second time.  Returns
- * the number of values written (<= capacity). */
+ * waves, [12] Fano attempts left to the device tail, [13] segments decoded a second time, [14] refined
+ * candidates whose result was consumed (the others: speculation cut by a subtraction), [15] subtractions.
+ * Returns the number of values written (<= capacity). */
 int wspr_last_timings(double *ms, int capacity);
+/* Worker threads of the library's host pools alive in this process (the threads that call into the library are
+ * not counted): what a rank adds to the host's load besides its callers -- 0 when its CPU share (WSPR_HOST_THREADS,
+ * or the share of a node-level call) is no larger than the slots it drives. */
+int wspr_host_pool_workers(void);
 /* Times `iters` passes of the FFT+sync stage (K1,K2,K3) on resident data with HIP events on the
  * launch stream, after one untimed pass.  ms must hold 8 doubles: ms[0] = K1 (sum over the segment chunks of a pass),
  * ms[1] = K2 (time average of every chunk + peak picking), ms[2] = K3, ms[3] = K1 launches per

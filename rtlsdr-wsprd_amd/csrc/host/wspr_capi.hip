@@ -132,7 +132,13 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
                                      options, decodes + (size_t)s * max_results, max_results, n_results + s, writeback);
         });
     try {
-        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        if (samples > wspr::kMaxSamples) {
+            // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
+            // its callers hold; this library's working rows are 45 000 samples, so a longer record is refused, not cut
+            fprintf(stderr, "libwspr_mi355x: samples = %d exceeds the %d this library decodes\n", samples, wspr::kMaxSamples);
+            for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+            return -2;
+        }
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
                             [&](Context& c, int lo, int n) {
                                 c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
@@ -157,7 +163,13 @@ int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, siz
                                            options, decodes + (size_t)s * max_results, max_results, n_results + s, trace + s);
         });
     try {
-        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        if (samples > wspr::kMaxSamples) {
+            // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
+            // its callers hold; this library's working rows are 45 000 samples, so a longer record is refused, not cut
+            fprintf(stderr, "libwspr_mi355x: samples = %d exceeds the %d this library decodes\n", samples, wspr::kMaxSamples);
+            for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+            return -2;
+        }
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
                             [&](Context& c, int lo, int n) {
                                 c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
@@ -182,7 +194,13 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
                                             options, decodes + (size_t)s * max_results, max_results, n_results + s);
         });
     try {
-        if (samples > wspr::kMaxSamples) samples = wspr::kMaxSamples;
+        if (samples > wspr::kMaxSamples) {
+            // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
+            // its callers hold; this library's working rows are 45 000 samples, so a longer record is refused, not cut
+            fprintf(stderr, "libwspr_mi355x: samples = %d exceeds the %d this library decodes\n", samples, wspr::kMaxSamples);
+            for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+            return -2;
+        }
         const float* di = static_cast<const float*>(d_idat);
         const float* dq = static_cast<const float*>(d_qdat);
         return decode_split(nseg, samples, options, decodes, max_results, n_results,
@@ -207,6 +225,22 @@ void wspr_shard_range(int nseg, int shard, int nshards, int* lo, int* hi) {
     if (hi) *hi = a + base + (shard < rem ? 1 : 0);
 }
 
+// The CPU share of a node-level call lasts as long as the call: raised on entry (to the largest share any call in
+// flight asks for), back to 1 when the last such call returns -- so that later single-device calls size their slots
+// and pick their Fano placement for the whole host again.  (Pools of contexts CREATED during the call keep the
+// share they were sized for.)
+namespace {
+struct NodeShareGuard {
+    static std::atomic<int>& active() { static std::atomic<int> n{0}; return n; }
+    explicit NodeShareGuard(int ndevices) {
+        active().fetch_add(1);
+        int prev = wspr::node_share().load();
+        while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    }
+    ~NodeShareGuard() { if (active().fetch_sub(1) == 1) wspr::node_share().store(1); }
+};
+}  // namespace
+
 // One host process, every GPU of the node: contiguous blocks of segments, one host thread per device,
 // each block through wspr_decode_batch() on its device (H2D of the block, decode, spots straight into the caller's
 // arrays).  No collective: the segments are independent (wsprd.c:478-479).
@@ -230,8 +264,7 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
     }
     if (options.usehashtable && nseg > 1)                // ordered by definition: nothing to spread
         return wspr_decode_batch(idat, qdat, nseg, samples, seg_stride, options, decodes, max_results, n_results, 0);
-    int prev = wspr::node_share().load();
-    while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    NodeShareGuard share(ndevices);
     const int lane0 = Context::lane();
     int home = 0;
     (void)hipGetDevice(&home);
@@ -242,7 +275,11 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
         wspr_shard_range(nseg, k, ndevices, &lo, &hi);
         if (hi <= lo) continue;
         th.emplace_back([=, &rcs] {
-            if (hipSetDevice(k % count) != hipSuccess) { rcs[k] = -1; return; }
+            if (hipSetDevice(k % count) != hipSuccess) {
+                rcs[k] = -1;
+                for (int s = lo; s < hi; ++s) n_results[s] = 0;
+                return;
+            }
             Context::bind_lane(lane0 + k / count);
             rcs[k] = wspr_decode_batch(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples,
                                        seg_stride, options, decodes + (size_t)lo * max_results, max_results,
@@ -253,6 +290,7 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
     (void)hipSetDevice(home);
     int rc = 0;
     for (int k = 0; k < ndevices; ++k) if (rcs[k] < rc) rc = rcs[k];
+    if (rc < 0) for (int s = 0; s < nseg; ++s) n_results[s] = 0;      // as the _device variant: a failed call reports no spots
     return rc;
 }
 
@@ -288,8 +326,7 @@ int wspr_decode_batch_node_device(const void* d_idat, const void* d_qdat, int sr
         (void)hipSetDevice(home);
         return rc;
     }
-    int prev = wspr::node_share().load();
-    while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    NodeShareGuard share(ndevices);
     const int lane0 = Context::lane();
     std::vector<int> rcs(ndevices, 0);
     std::vector<std::thread> th;
@@ -420,6 +457,8 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
     } catch (const std::exception& e) { return fail("wspr_stage_candidates", e); }
 }
 
+int wspr_host_pool_workers(void) { return wspr::pool_workers_alive().load(); }
+
 int wspr_last_timings(double* ms, int capacity) {
     // times: the slowest slot (slots run concurrently); counts (index >= 7): summed over the slots
     try {
@@ -520,7 +559,7 @@ int wspr_set_device(int device) {
 }
 
 int wspr_bind_thread_lane(int lane) {
-    // the last lane is the receiver sessions' (wspr_session_feed runs beside a decode): callers get 0..3
+    // the last lane is the receiver sessions' (wspr_session_feed runs beside a decode): callers get 0 .. kUserLanes - 1
     Context::bind_lane(lane < 0 ? 0 : (lane >= Context::kUserLanes ? Context::kUserLanes - 1 : lane));
     return Context::lane();
 }

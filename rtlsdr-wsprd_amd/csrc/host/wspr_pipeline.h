@@ -19,6 +19,8 @@ namespace wspr {
 std::atomic<unsigned>& fano_fast_budget();
 // -1 automatic, 0 host pool only, 1 device search for every attempt of a batch (see wspr_pipeline.hip)
 std::atomic<int>& fano_device_setting();
+// worker threads of all host pools alive in this process
+std::atomic<int>& pool_workers_alive();
 // shards of a node-level call sharing this host's CPUs (see wspr_decode_batch_node)
 std::atomic<int>& node_share();
 // CUs the front end (K0) may occupy, 0 = all (wspr_set_front_end_cus / WSPR_K0_CUS)

@@ -78,6 +78,9 @@ struct PinBuf {
 // wake up late cost nothing, and a late thread holding an exhausted old job can never
 // touch a newer one.  Idle workers sleep on a condition variable; only the caller spins,
 // briefly, for the last tasks to finish.
+// worker threads of all host pools alive in this process (the calling threads of the pools are not counted)
+std::atomic<int>& pool_workers_alive() { static std::atomic<int> n{0}; return n; }
+
 class Pool {
     struct Job {
         const std::function<void(int)>* fn;
@@ -88,8 +91,10 @@ class Pool {
 public:
     explicit Pool(int n) {
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        pool_workers_alive().fetch_add((int)workers_.size());
     }
     ~Pool() {
+        pool_workers_alive().fetch_sub((int)workers_.size());
         quit_.store(true);
         { std::lock_guard<std::mutex> g(m_); ++epoch_; }
         cv_.notify_all();

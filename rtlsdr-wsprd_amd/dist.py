@@ -102,11 +102,34 @@ def in_rank_order(fn):
     keeps the sharded driver correct for it."""
     import os
     world, rank = dist.get_world_size(), dist.get_rank()
-    # the turns only mean something if every rank reads and writes the SAME hashtable.txt
-    cwds = [None] * world
-    dist.all_gather_object(cwds, (os.uname().nodename, os.path.realpath(os.getcwd())))
-    if len(set(cwds)) != 1:
-        raise RuntimeError("in_rank_order: the ranks do not share one working directory (hashtable.txt): %r" % (cwds,))
+    # The turns only mean something if every rank reads and writes the SAME hashtable.txt.  Evidence of the same
+    # directory, not of the same path: rank 0 drops a nonce file into its working directory and every rank must find
+    # it with that content in ITS working directory -- true for ranks of one node and for ranks of several nodes on
+    # a shared file system alike (paths or host names need not match).
+    import uuid
+    nonce = [uuid.uuid4().hex if rank == 0 else None]
+    dist.broadcast_object_list(nonce, src=0)
+    probe = ".wspr_rank_order_%s" % nonce[0]
+    if rank == 0:
+        with open(probe, "w") as f:
+            f.write(nonce[0])
+            f.flush()
+            os.fsync(f.fileno())
+    dist.barrier()
+    try:
+        with open(probe) as f:
+            seen = f.read() == nonce[0]
+    except OSError:
+        seen = False
+    sees = [None] * world
+    dist.all_gather_object(sees, (seen, os.uname().nodename, os.getcwd()))
+    if rank == 0:
+        try:
+            os.unlink(probe)
+        except OSError:
+            pass
+    if not all(x[0] for x in sees):
+        raise RuntimeError("in_rank_order: the ranks do not share one working directory (hashtable.txt): %r" % (sees,))
     out, err = None, None
     for r in range(world):
         if r == rank:

@@ -294,3 +294,42 @@ def test_in_rank_order_does_not_hang_when_a_rank_fails():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0].startswith("own: decoder said no") and got[1].startswith("other:")
+
+
+def _cwd_worker(rank, world, port, q, dirs):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.chdir(dirs[rank])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_wsprd_amd import dist as wd
+    try:
+        q.put((rank, "ran: %r" % (wd.in_rank_order(lambda: rank),)))
+    except RuntimeError as e:
+        q.put((rank, "refused: %s" % str(e)[:60]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_in_rank_order_wants_evidence_of_one_directory(tmp_path, shared):
+    """Ranks in the same directory (reached through different paths: a symlink) take their turns; ranks in different
+    directories would each keep their own hashtable.txt and are refused (round-3 advisor finding: the check compared
+    host names and paths, which refused every multi-node job and says nothing about what the paths point at)."""
+    a = tmp_path / "a"; a.mkdir()
+    if shared:
+        b = tmp_path / "b"; b.symlink_to(a, target_is_directory=True)
+    else:
+        b = tmp_path / "b"; b.mkdir()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000 + (1 if shared else 0)
+    procs = [ctx.Process(target=_cwd_worker, args=(r, 2, port, q, [str(a), str(b)])) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if shared:
+        assert got == {0: "ran: 0", 1: "ran: 1"} and not [f for f in os.listdir(a) if f.startswith(".wspr_rank_order")]
+    else:
+        assert got[0].startswith("refused:") and got[1].startswith("refused:")

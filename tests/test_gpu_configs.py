@@ -65,10 +65,10 @@ def test_config3_8192_segments_x_10_signals(env):
     h = w.BatchDecoder(nseg // 2, 32)
     h.decode(I[: nseg // 2].contiguous(), Q[: nseg // 2].contiguous())
     assert [[_tup(x) for x in h.spots(s)] for s in range(nseg // 2)] == full[: nseg // 2]
-    # exact agreement with the CPU oracle on 16 sampled segments (all fields of all spots, in order); a longer
+    # exact agreement with the CPU oracle on 128 sampled segments (all fields of all spots, in order); a longer
     # soak: WSPR_CONFIG3_ORACLE_SEGMENTS=512 (the oracle calls run on a thread pool: ctypes drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "16"))
+    nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "128"))
     picks = list(range(5, nseg, nseg // nsample))
     Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
@@ -259,9 +259,13 @@ def test_bench_gpus_2_spawns_two_ranks_sharing_the_one_gpu():
     refuses two ranks on one device) -- everything else is the code the 2/4/8-GPU runs execute."""
     d = _bench_line(["--gpus", "2", "--config", "2", "--segments", "256", "--steps", "6", "--warmup", "2",
                      "--no-cpu-baseline", "--min-seconds", "0"],
-                    _no_launcher_env(WSPR_BENCH_SHARE_GPU="1", WSPR_BENCH_BACKEND="gloo"))
+                    _no_launcher_env(WSPR_BENCH_SHARE_GPU="1", WSPR_BENCH_BACKEND="gloo", WSPR_HOST_THREADS="2"))
     ok, sent = map(int, d["decoded_ok"].split("/"))
     assert d["n_gpus"] == 2 and ok >= 0.95 * sent and d["false_decodes"] == 0
+    # the line says that the two ranks sat on ONE device (round-3 advisor finding), and a rank with the CPU share of an
+    # 8-rank job (2 of these boxes' 16 CPUs) adds no pool threads to the lane threads that drive its batches
+    assert d["distinct_devices"] == 1 and d["devices_shared"] is True
+    assert d["host_threads"] == 2 and d["host_pool_workers"] == 0
     assert d["config"]["segments_per_gpu"] == 256 and d["spots_total"] >= 2 * ok - 4        # both ranks' records arrived
     assert d["fanout_check"]["segments_scattered_from_rank0"] == 8
     assert d["fanout_check"]["equal_to_rank0_own_decode"] == "8/8"

@@ -352,7 +352,7 @@ def random_scenes(count=None, seed=None):
     sigma = np.sqrt((375.0 / 2500.0) / 2.0)
     t23 = ["PJ4/K1ABC 37", "K1ABC/7 33", "<PJ4/K1ABC> FK52UD 37"]
     Is, Qs = [], []
-    for scene in range(int(os.environ.get("WSPR_SCENES", "40")) if count is None else count):      # (a longer soak: WSPR_SCENES=400)
+    for scene in range(int(os.environ.get("WSPR_SCENES", "120")) if count is None else count):      # (a longer soak: WSPR_SCENES=400)
         I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
         nsig = 0 if scene == 0 else int(rng.integers(1, 7))
         base = rng.uniform(-125, 125, nsig)
@@ -412,7 +412,7 @@ def crowded_scenes(count, seed=77):
 @pytest.mark.parametrize("opts", [{}, {"npasses": 3}, {"subtraction": 0}, {"quickmode": 1}, {"npasses": 1}])
 def test_crowded_band_equals_oracle(w, opts):
     """Crowded bands under every option set: spot for spot the oracle's (a longer soak: WSPR_CROWDED=200)."""
-    I, Q = crowded_scenes(int(os.environ.get("WSPR_CROWDED", "6")))
+    I, Q = crowded_scenes(int(os.environ.get("WSPR_CROWDED", "12")))
     got = w.wspr_decode_batch(I, Q, w.default_options(**opts), max_results=100)
     most = 0
     for s in range(I.shape[0]):
@@ -474,6 +474,29 @@ def test_empty_and_degenerate_inputs(w):
     ref, _, _ = ol.decode(np.concatenate([I[:40000], np.zeros(5000, np.float32)]),
                           np.concatenate([Q[:40000], np.zeros(5000, np.float32)]), 40000)
     assert [_spot_tuple(x) for x in spots] == [_spot_tuple(x) for x in ref]
+
+
+def test_a_record_longer_than_45000_samples_is_refused(w):
+    """The reference sizes its FFT bank from `samples` (wsprd.c:516); this library's rows hold 45 000 samples and a
+    longer record is an error (-2, no spots, inputs untouched), not a silently shortened decode."""
+    import ctypes as C
+    n = NS + 512
+    I = np.full(n, 0.25, np.float32)
+    Q = np.full(n, -0.25, np.float32)
+    I0, Q0 = I.copy(), Q.copy()
+    out = (w.decoder_results * 100)()
+    nres = C.c_int(7)
+    assert w.lib().wspr_decode(ol.ptr(I), ol.ptr(Q), n, w.default_options(), C.addressof(out), C.addressof(nres)) == -2
+    assert nres.value == 0 and np.array_equal(I, I0) and np.array_equal(Q, Q0)
+    nb = (C.c_int * 2)(5, 5)
+    outb = (w.decoder_results * 20)()
+    I2, Q2 = np.stack([I, I]), np.stack([Q, Q])
+    assert w.lib().wspr_decode_batch(ol.ptr(I2), ol.ptr(Q2), 2, n, n, w.default_options(), C.addressof(outb), 10,
+                                     C.addressof(nb), 0) == -2
+    assert list(nb) == [0, 0]
+    # exactly 45 000 is the reference's own case
+    spots, _, _ = w.wspr_decode(I[:NS], Q[:NS], NS)
+    assert spots == []
 
 
 # ------------------------------------------------------------------ K0

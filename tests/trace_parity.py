@@ -81,7 +81,7 @@ def main(argv):
             import bench
             dev = torch.device("cuda", 0)
             torch.cuda.set_device(0)
-            n = int(os.environ.get("WSPR_TRACE_CONFIG3", "16"))
+            n = int(os.environ.get("WSPR_TRACE_CONFIG3", "64"))
             I, Q, _ = bench.synth_batch_gpu(n, 4321, dev, 10, -10.0, -28.0, 0.3)
             print(what, check(I.cpu().numpy(), Q.cpu().numpy(), w, ol, None, what), flush=True)
         else:
