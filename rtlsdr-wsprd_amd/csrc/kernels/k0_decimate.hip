@@ -309,6 +309,140 @@ void cic_block_sums_fast_kernel(const uint8_t* __restrict__ raw, size_t bytes_pe
     }
 }
 
+// ---- whole segments, block sums on the MATRIX pipe (round 4) -------------------------------------------------------
+// The block sums are int8 x int8 -> int32 contractions: S = sum_r (+-1 / 0) x_r,  W = sum_r (R - off_r)(+-1 / 0) x_r.
+// cic_block_sums_fast_kernel forms them with sixteen v_dot4_i32_i8 per 16-byte vector: 37 vector instructions per
+// vector, which is why the front end needs every CU's vector pipes to reach HBM's rate and cannot run beside the
+// decoder ("K0 and the decoder").  V_MFMA_I32_16X16X64_I8 takes the same contraction off the vector pipes:
+//   B (data)    lane l of a group of 64 consecutive vectors holds vector v0 + 64 g + l: column n = l & 15, k-block l >> 4;
+//   A (weights) row i = lane & 15, k-block lane >> 4, one weight per byte of a vector (tools/mfma_i8_probe.hip):
+//               row 0 / 1   the mixer's +-1 / 0 pattern for x_i / x_q              -> t   (sum over the column's vectors)
+//               row 2 / 3   the same times -k, k = 0..7 the sample's place in the vector  -> nu  (-sum k x_k)
+//               row 4 / 5   the same times the k-block 0..3                        -> sum blk * t
+//   C (int32)   accumulates over the 13 groups of a block; magnitudes stay below 2^20, far from the accumulator's range
+//               (the large factors -- R - off up to 6 401 -- are applied afterwards in wrapping 32-bit arithmetic).
+// With v - v0 = 64 g + 16 blk + n the weight of vector v is wb0 - 8 (v - v0), so per block
+//   W = sum_n [(wb0 - 8 n) T_n + N_n] - 128 sum_n B_n - 512 sum_g g T_g,   sum_g g T_g = G T - sum_{j=1..G} P_j
+// (T_n, N_n, B_n: rows 0/1, 2/3, 4/5 of column n; P_j: row 0/1 after j groups, kept as one running add per group).
+// What is left on the vector pipes per 16 bytes: the sign flip (4), the zero-byte test (8), two adds.  The two edge
+// vectors of a block, and a block that holds a raw 0x00 byte, take the paths of the kernel above.
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct alignas(16) MfmaWeights { signed char w[4][64][16]; };     // [group % 4][lane][byte of a vector]
+constexpr MfmaWeights make_k0_weights() {
+    MfmaWeights m{};
+    for (int j = 0; j < 4; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, blk = lane >> 4;
+            for (int k = 0; k < 8; ++k) {
+                // x_i = (+a, -b, -a, +b)[k & 3], x_q = (+b, +a, -b, -a)[k & 3]   (a = byte 2k, b = byte 2k + 1)
+                const int ia[4] = {1, 0, -1, 0}, ib[4] = {0, -1, 0, 1}, qa[4] = {0, 1, 0, -1}, qb[4] = {1, 0, -1, 0};
+                const int wa = (row & 1) ? qa[k & 3] : ia[k & 3], wb = (row & 1) ? qb[k & 3] : ib[k & 3];
+                const int f = row < 2 ? 1 : row < 4 ? -k : row < 6 ? blk : row < 8 ? j : 0;
+                m.w[j][lane][2 * k] = (signed char)(f * wa);
+                m.w[j][lane][2 * k + 1] = (signed char)(f * wb);
+            }
+        }
+    return m;
+}
+__constant__ MfmaWeights kK0Weights = make_k0_weights();
+
+__device__ __forceinline__ void zero_byte_test(const u4 q, unsigned (&zacc)[4]) {
+    zacc[0] |= (q.x - 0x01010101u) & ~q.x;
+    zacc[1] |= (q.y - 0x01010101u) & ~q.y;
+    zacc[2] |= (q.z - 0x01010101u) & ~q.z;
+    zacc[3] |= (q.w - 0x01010101u) & ~q.w;
+}
+
+__global__ __launch_bounds__(256)
+void cic_block_sums_mfma_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks, int nseg,
+                                int32_t* __restrict__ sums) {
+    // grid: (quads of blocks, segments), or -- gridDim.y == 1 with fewer workgroups than there are quads -- a RESIDENT
+    // grid whose workgroups take the (segment, quad) items in turn (WSPR_K0_RESIDENT: the front end then holds a fixed
+    // number of wave slots per CU and leaves the others, and most of the vector pipes, to the decoder's kernels)
+    const int lane = threadIdx.x & 63;
+    const int quads = (nblocks + 3) / 4;
+    const bool resident = gridDim.y == 1 && nseg > 1;
+    const int items = resident ? quads * nseg : 1;
+  for (int item = resident ? (int)blockIdx.x : 0; item < items; item += resident ? (int)gridDim.x : 1) {
+    const int seg = resident ? item / quads : (int)blockIdx.y;
+    const int b = (resident ? item - seg * quads : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b >= nblocks) continue;                                   // wave-uniform
+    const int lo = b * kR, hi = lo + kR;                          // the block's samples
+    const int vi_lo = (lo + 7) >> 3, vi_hi = hi >> 3;             // its interior vectors [vi_lo, vi_hi): 799 or 800
+    const int v_max = (int)((bytes_per_seg / 2 + 7) >> 3);        // vectors in a row
+    const u4* __restrict__ vec = reinterpret_cast<const u4*>(raw + (size_t)seg * bytes_per_seg);
+    v4i A[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A[j] = *reinterpret_cast<const v4i*>(kK0Weights.w[j][lane]);
+    v4i C = {0, 0, 0, 0};
+    unsigned zacc[4] = {0u, 0u, 0u, 0u};
+    auto group = [&](const u4 q, const v4i& Aj) {
+        zero_byte_test(q, zacc);
+        const v4i B = {(int)(q.x ^ 0x80808080u), (int)(q.y ^ 0x80808080u), (int)(q.z ^ 0x80808080u), (int)(q.w ^ 0x80808080u)};
+        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aj, B, C, 0, 0, 0);
+    };
+    // the thirteenth group: the 31 or 32 interior vectors behind the twelve full groups (lanes beyond them carry zeros)
+    const int vt = vi_lo + 768 + lane;
+    const bool tail_lane = vt < vi_hi;
+    // the two edge vectors (lanes 62, 63 of the vector path): one before the first interior vector, one behind the last
+    int ve = 0, k_lo = 0, k_hi = 0;
+    if (lane == 62) { ve = vi_lo - 1; k_lo = lo - 8 * ve; k_hi = (k_lo < 8) ? 8 : 0; }       // k_lo == 8: the block starts on a vector
+    if (lane == 63) { ve = vi_hi; k_hi = hi - 8 * ve; }                                      // 0: it ends on one
+    const u4* __restrict__ p0 = vec + vi_lo + lane;
+    // groups g = 4 s + j: rows 6 / 7 weigh a group by j; the super-group index s is applied to what rows 0 / 1 hold after
+    // every fourth group (P1, P2, P3: the sums before super-groups 1, 2, 3)
+    unsigned pI = 0u, pQ = 0u;
+    u4 qa[4], qb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 64 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qb[u] = __builtin_nontemporal_load(p0 + 256 + 64 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) group(qa[u], A[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 512 + 64 * u);
+    pI += (unsigned)C[0]; pQ += (unsigned)C[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) group(qb[u], A[u]);
+    u4 qt = __builtin_nontemporal_load(vec + min(vt, v_max - 1));
+    const u4 qe = __builtin_nontemporal_load(vec + min(max(ve, 0), v_max - 1));
+    pI += (unsigned)C[0]; pQ += (unsigned)C[1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) group(qa[u], A[u]);
+    pI += (unsigned)C[0]; pQ += (unsigned)C[1];
+    if (!tail_lane) qt = (u4){0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};           // x = 0 after the sign flip; no zero byte
+    group(qt, A[0]);                                                                         // group 12 = super-group 3, j = 0
+    // sum_s s T_s over the four super-groups = 3 T - (P1 + P2 + P3)
+    unsigned acc[4] = {0u, 0u, 0u, 0u}, zedge[4] = {0u, 0u, 0u, 0u};
+    block_sum_vector<true>(qe, kR + lo - 8 * ve, k_lo, k_hi, acc, zedge);                     // non-zero in lanes 62, 63 only
+    if (lane >= 62) { zacc[0] |= zedge[0]; zacc[1] |= zedge[1]; zacc[2] |= zedge[2]; zacc[3] |= zedge[3]; }
+    if (__any(((zacc[0] | zacc[1] | zacc[2] | zacc[3]) & 0x80808080u) != 0u)) {                      // clipping at the negative rail: exact path
+        unsigned ex[4] = {0u, 0u, 0u, 0u};                         // (its own array: the call takes its address)
+        for (int v = vi_lo - 1 + lane; v <= vi_hi; v += 64) {
+            if (v < 0 || v >= v_max) continue;
+            const u4 q = __builtin_nontemporal_load(vec + v);
+            block_sum_vector_exact(q, 8 * v, lo, hi, ex);
+        }
+        acc[0] = ex[0]; acc[1] = ex[1]; acc[2] = ex[2]; acc[3] = ex[3];
+    } else if (lane < 16) {
+        // weight of vector v0 + 256 s + 64 j + 16 blk + n:  wb0 - 8 (256 s + 64 j + 16 blk + n)
+        const unsigned wb = (unsigned)(kR + lo - 8 * vi_lo) - 2048u * 3u - 8u * (unsigned)lane;
+        acc[0] += (unsigned)C[0];
+        acc[1] += (unsigned)C[1];
+        acc[2] += wb * (unsigned)C[0] + 2048u * pI + (unsigned)C[2];
+        acc[3] += wb * (unsigned)C[1] + 2048u * pQ + (unsigned)C[3];
+    } else if (lane < 32) {
+        acc[2] -= 128u * (unsigned)C[0] + 512u * (unsigned)C[2];   // rows 4 / 5: k-block times t; rows 6 / 7: j times t
+        acc[3] -= 128u * (unsigned)C[1] + 512u * (unsigned)C[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = wave_sum(acc[i]);
+        if (lane == 0) sums[((size_t)seg * nblocks + b) * 4 + i] = (int32_t)s;
+    }
+  }
+}
+
 // Integrators at the decimation instants by parallel prefix sums (exact: arithmetic mod 2^32 is
 // associative).  With P1 = inclusive scan of S:  I1(b) = P1[b],  I2(b) = scan_b( R*P1[b-1] + W_b ).
 // One workgroup per (segment, rail); thread t owns a contiguous chunk of blocks.
@@ -493,9 +627,23 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     // whole segments take the wave-per-block kernel (sample indices fit 31 bits: rows below 4 GiB);
     // WSPR_K0_KERNEL=general keeps them on the kernel that also serves carried states
     static const bool general = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'g'; }();
+    // WSPR_K0_KERNEL=dot4: whole segments on the vector-pipe kernel (sixteen v_dot4 per vector) instead of the MFMA one
+    static const bool dot4 = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'd'; }();
     if (!states && !general && bytes_per_seg < ((size_t)1 << 32)) {
-        hipLaunchKernelGGL(cic_block_sums_fast_kernel, dim3((nblocks + 3) / 4, nseg), dim3(256), 0, st, raw,
-                           bytes_per_seg, nblocks, sums);
+        if (dot4)
+            hipLaunchKernelGGL(cic_block_sums_fast_kernel, dim3((nblocks + 3) / 4, nseg), dim3(256), 0, st, raw,
+                               bytes_per_seg, nblocks, sums);
+        else {
+            // WSPR_K0_RESIDENT=p: a resident grid of p workgroups per CU instead of one workgroup per four blocks
+            static const int per_cu = [] { const char* e = getenv("WSPR_K0_RESIDENT"); return e ? atoi(e) : 0; }();
+            const int quads = (nblocks + 3) / 4;
+            if (per_cu > 0 && nseg > 1 && (long)quads * nseg > 256L * per_cu)
+                hipLaunchKernelGGL(cic_block_sums_mfma_kernel, dim3(256 * per_cu, 1), dim3(256), 0, st, raw, bytes_per_seg,
+                                   nblocks, nseg, sums);
+            else
+                hipLaunchKernelGGL(cic_block_sums_mfma_kernel, dim3(quads, nseg), dim3(256), 0, st, raw, bytes_per_seg,
+                                   nblocks, nseg, sums);
+        }
         hipLaunchKernelGGL(cic_comb_fir_kernel, dim3((nblocks + 255) / 256, nseg), dim3(256), 0, st, sums, nblocks,
                            dI, dQ, n_out);
         return;
