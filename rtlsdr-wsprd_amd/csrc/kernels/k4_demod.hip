@@ -14,7 +14,7 @@
 //
 // Kernels in this file, by the stage they serve (every one performs demod_kernel's operations per accumulator):
 //   general               demod_kernel                 any mode, any drift; exported sync_and_demodulate()
-//   mode 0, no drift      demod_lag3_kernel            three symbols per lane, table through the scalar cache
+//   mode 0, no drift      demod_lagsys_kernel          a strided correlation, samples in registers and handed lane to lane
 //   mode 0, drift         demod_drift_kernel           three lags per lane, per-symbol tables in an LDS ring
 //   mode 0 (quick mode), ladder rungs (mode 2, 43 lags)
 //                         phasor_table_kernel + demod_tile_kernel<STEP, shared> + demod_metric_kernel
@@ -504,130 +504,6 @@ void demod_drift_kernel(const float* __restrict__ dI, const float* __restrict__ 
 }
 
 // -----------------------------------------------------------------------------
-// Lag scan (mode 0: 33 lags, step 8) of a DRIFT-FREE candidate, three symbols per lane.
-//
-// The candidate has ONE phasor table, read through the scalar cache into SGPR operands.  With one (symbol, lag)
-// per lane (demod_tile_kernel<8, true>) a wave issues 16 packed instructions per table entry and then waits for
-// the next scalar load and LDS read: its vector pipe is busy 61 % of the time (SQ counters).  Here a lane runs
-// the same lag of THREE consecutive symbols (lane = (symbol triple q, lag m), L = 33 q + m, 54 x 33 = 1 782
-// lanes = 7 workgroups of 256 at 99.4 %): a table entry serves three 16-instruction accumulator updates, the
-// address arithmetic is shared, and consecutive lanes read consecutive 8-byte words of the lag-step-transposed
-// sample tile (conflict-free without padding).  Same operations per accumulator as demod_kernel => identical bits.
-constexpr int kL3Threads = 256;
-constexpr int kL3Lanes = (kNSymD / 3) * 33;                 // 1 782 (symbol triple, lag) pairs per candidate
-constexpr int kL3Wgs = (kL3Lanes + kL3Threads - 1) / kL3Threads;
-constexpr int kL3MaxSyms = 3 * ((kL3Threads + 32) / 33 + 1);       // symbols one workgroup can touch: 27
-constexpr int kL3Span = kSps * kL3MaxSyms + 8 * 32;         // samples staged per workgroup
-constexpr int kL3Pitch = kL3Span / 8 + 1;                   // 8-byte words per tile row
-
-__global__ __launch_bounds__(kL3Threads)
-void demod_lag3_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                       const FineState* __restrict__ items, const int* __restrict__ item_list,
-                       const float* __restrict__ tabs, float4* __restrict__ pw_out) {
-    extern __shared__ __attribute__((aligned(16))) char l3_smem[];
-    float2* tile = reinterpret_cast<float2*>(l3_smem);
-    constexpr int nlag = 33;
-    const int item = item_list[blockIdx.y];
-    const FineState st = items[item];
-    const int tid = threadIdx.x;
-    const int L0 = blockIdx.x * kL3Threads, L = L0 + tid;
-    const int q0 = L0 / nlag;                                // first symbol triple of this workgroup
-    const int q1 = min(kNSymD / 3 - 1, (L0 + kL3Threads - 1) / nlag);
-    const int sym0 = 3 * q0, nsym = 3 * (q1 - q0 + 1);
-    const int span = kSps * nsym + 8 * 32;
-    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
-    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int kbase = st.shift_coarse - 128 + kSps * sym0;
-    // every load of the tile is issued before the first is waited for (one trip to memory instead of seven):
-    // addresses are clamped into the segment and the value is dropped where the reference skips the sample
-    constexpr int kIter = kL3Span / kL3Threads;               // 28 samples per lane
-    static_assert(kL3Span % kL3Threads == 0, "tile rows per lane");
-    float2 v[kIter];
-#pragma unroll
-    for (int u = 0; u < kIter; ++u) {
-        const int kc = min(max(kbase + tid + u * kL3Threads, 0), np - 1);
-        v[u] = make_float2(xi[kc], xq[kc]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < kIter; ++u) {
-        const int e = tid + u * kL3Threads, k = kbase + e;
-        const bool ok = (e < span) && (k > 0) && (k < np);   // wsprd.c:199; zero-fill == skip (x*c = 0 adds exactly)
-        tile[(e & 7) * kL3Pitch + (e >> 3)] = ok ? v[u] : make_float2(0.0f, 0.0f);
-    }
-    __syncthreads();
-    if (L >= kL3Lanes) return;
-    const int q = L / nlag, m = L - q * nlag;
-    // e = 8 m + 256 (sym - sym0) + j: row j & 7, column m + 32 (sym - sym0) + (j >> 3)
-    const float2* __restrict__ col = tile + m + (kSps / 8) * (3 * (q - q0));
-    const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
-                                      (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
-    ToneAcc acc[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[r].clear();
-    // Two steps form a stage: their table entries (one 64-byte scalar load) and their 2 x 3 samples.  The loads
-    // of stage k+1 are issued before stage k is consumed and waited for one stage later, when they are ~800
-    // cycles old: scalar loads return out of order, so every wait on them is lgkmcnt(0); placed by hand at the
-    // top of a stage it only sees loads that have had a whole stage to land.
-    struct Stage { float4 c[2], s[2]; float2 d[2][3]; };
-    auto issue = [&](Stage& g, int j) {                      // j even; clamped past the end (values unused)
-        const int jj = j < kSps ? j : 0;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            g.c[u] = gtab[2 * (jj + u)];
-            g.s[u] = gtab[2 * (jj + u) + 1];
-            const float2* __restrict__ t0 = col + ((jj + u) >> 3) + ((jj + u) & 7) * kL3Pitch;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) g.d[u][r] = t0[(kSps / 8) * r];
-        }
-    };
-    auto consume = [&](const Stage& g) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float4 c4 = g.c[u], s4 = g.s[u];
-            const v2f c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w}, s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
-            v2f p[3][8];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const v2f xx = {g.d[u][r].x, g.d[u][r].x}, yy = {g.d[u][r].y, g.d[u][r].y};
-                p[r][0] = xx * c01; p[r][1] = xx * c23; p[r][2] = xx * s01; p[r][3] = xx * s23;
-                p[r][4] = yy * s01; p[r][5] = yy * s23; p[r][6] = yy * c01; p[r][7] = yy * c23;
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {               // ai = (ai + x*c) + y*s ; aq = (aq - x*s) + y*c (wsprd.c:200-207)
-                acc[r].i01 = acc[r].i01 + p[r][0]; acc[r].i23 = acc[r].i23 + p[r][1];
-                acc[r].q01 = acc[r].q01 - p[r][2]; acc[r].q23 = acc[r].q23 - p[r][3];
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                acc[r].i01 = acc[r].i01 + p[r][4]; acc[r].i23 = acc[r].i23 + p[r][5];
-                acc[r].q01 = acc[r].q01 + p[r][6]; acc[r].q23 = acc[r].q23 + p[r][7];
-            }
-        }
-    };
-    Stage A, B;
-    issue(A, 0);
-#pragma unroll 1
-    for (int j0 = 0; j0 < kSps; j0 += 4) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): stage A has landed
-        __builtin_amdgcn_sched_barrier(0);
-        issue(B, j0 + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(A);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // stage B has landed
-        __builtin_amdgcn_sched_barrier(0);
-        issue(A, j0 + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(B);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-        pw_out[((size_t)item * nlag + m) * kNSymD + 3 * q + r] = acc[r].amplitudes();
-}
-
-// -----------------------------------------------------------------------------
 // Lag scan (mode 0: 33 lags, step 8) of a DRIFT-FREE candidate as ONE strided correlation, samples in registers.
 //
 // With one table for the whole frame the accumulator of (symbol s, lag m) is
@@ -648,9 +524,6 @@ void demod_lag3_kernel(const float* __restrict__ dI, const float* __restrict__ d
 // Per 8 steps and lane: 8 x 16 x ROWS packed multiplies/adds, 16 DPP moves, 16 uniform loads.
 // u = 5184 (symbol 161 at lag 32) has no lane: one extra workgroup per 64 candidates sums it, a candidate per lane.
 // Same operations per accumulator as demod_kernel => identical bits.
-#ifndef LAGSYS_EXP
-#define LAGSYS_EXP 0
-#endif
 constexpr int kSysRows = 3;
 constexpr int kSysU = 64 * kSysRows;                        // outputs per wave
 constexpr int kSysOutputs = 32 * kNSymD;                    // u = 0 .. 5183 (+ u = 5184: the extra)
@@ -749,15 +622,11 @@ __device__ __forceinline__ void lagsys_wave(const float* __restrict__ xi, const 
             v2f (&F)[8] = S[(bb + R) % NS];
             const v2f (&G)[8] = S[bb % NS];
 #pragma unroll
-#if !(LAGSYS_EXP & 1)
             for (int i = 0; i < 8; ++i) {
                 F[i].x = wave_shl1(F[i].x, G[i].x);
                 F[i].y = wave_shl1(F[i].y, G[i].y);
             }
-#endif
-#if !(LAGSYS_EXP & 2)
             fresh(S[bb % NS]);                               // wanted one block from now
-#endif
         }
     }
 }
@@ -794,19 +663,14 @@ __device__ __noinline__ void lagsys_edge_wave(const float* __restrict__ xi, cons
     lagsys_store(acc, u0, item, pw_out);
 }
 
-#ifndef LAGSYS_WAVES
-#define LAGSYS_WAVES 3
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LAGSYS_WAVES, LAGSYS_WAVES)))
+// 154 VGPRs, three waves per SIMD (a 128-register build spills 28 dwords into the hot loop and runs 12 % slower)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                          const FineState* __restrict__ items, const int* __restrict__ item_list, int nitems,
                          const float* __restrict__ tabs, float4* __restrict__ pw_out) {
     constexpr int nlag = 33;
     const int lane = threadIdx.x;
     if (blockIdx.x == kSysWaves) {
-#if (LAGSYS_EXP & 4)
-        return;
-#endif
         // u = 5184: (symbol 161, lag 32) of 64 candidates, one per lane
         if (blockIdx.y & 63) return;
         const int pos = blockIdx.y + lane;
@@ -1263,12 +1127,9 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     };
     auto threads = [&](int syms) { return dim3(((syms * nlag + 63) / 64) * 64); };
     float4* pw4 = reinterpret_cast<float4*>(pw);
-    // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one symbol per lane)
-    static const bool lag3_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
-    // WSPR_K4_LAG=lag3: the LDS-tiled three-symbols-per-lane kernel instead of the register-resident correlation
-    static const bool lagsys_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !e || !e[0] || e[0] == 's'; }();
-    static std::atomic<unsigned> l3_opted{0};
-    if (lag3_kernel) lds_opt_in(reinterpret_cast<const void*>(&demod_lag3_kernel), 8 * kL3Pitch * sizeof(float2), l3_opted);
+    // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one (symbol, lag) per lane,
+    // samples in LDS) instead of the register-resident correlation
+    static const bool lagsys_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
     static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
@@ -1276,10 +1137,6 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
         if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
             hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves + 1, n_shared), dim3(64), 0, st, dI, dQ,      \
                                samples, items, list_shared, n_shared, tabs, pw4);                                \
-        else if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lag3_kernel)                            \
-            hipLaunchKernelGGL(demod_lag3_kernel, dim3(kL3Wgs, n_shared), dim3(kL3Threads),                      \
-                               (size_t)8 * kL3Pitch * sizeof(float2), st, dI, dQ, samples, items, list_shared,   \
-                               tabs, pw4);                                                                       \
         else if (n_shared > 0)                                                                                   \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
                                threads(kTileSymsShared), tile_bytes(kTileSymsShared), st, dI, dQ, samples,        \

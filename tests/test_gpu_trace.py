@@ -1,5 +1,5 @@
 """The production K4/K5 kernels per candidate (round-2 verdict, weak #2): the exported sync_and_demodulate() drives the
-GENERAL demod kernel, so its parity tests say nothing about demod_lag3 / demod_drift / freq_scalar / freq_drift / the
+GENERAL demod kernel, so its parity tests say nothing about demod_lagsys / demod_drift / freq_scalar / freq_drift / the
 tiled ladder kernel, and spot-level tests only see candidates that decode.  wspr_decode_batch_trace() records what those
 kernels produced for every candidate the reference's loop enters; it must equal the oracle's trace field for field.
 The library's environment switches are read once per process, so the alternatives that are kept in the tree are run
@@ -58,7 +58,7 @@ def _run_with(env, sets):
     assert r.returncode == 0 and "TRACE PARITY OK" in r.stdout, (env, r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env", [{"WSPR_K4_LAG": "tile"}, {"WSPR_K4_LAG": "lag3"}, {"WSPR_K4_DRIFT": "tile"}, {"WSPR_FANO_DEVICE": "1"},
+@pytest.mark.parametrize("env", [{"WSPR_K4_LAG": "tile"}, {"WSPR_K4_DRIFT": "tile"}, {"WSPR_FANO_DEVICE": "1"},
                                  {"WSPR_FANO_DEVICE": "0"}, {"WSPR_K3_KERNEL": "lane", "WSPR_K1_FUSED": "1"},
                                  {"WSPR_K3_KERNEL": "waves", "WSPR_K1_FUSED": "0", "WSPR_SLOTS": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))

@@ -10,13 +10,13 @@ __global__ void k(int* o) {
 template <int CTRL>
 void run(const char* name) {
     int* d; int h[64];
-    hipMalloc(&d, 256);
+    (void)hipMalloc(&d, 256);
     hipLaunchKernelGGL(k<CTRL>, dim3(1), dim3(64), 0, 0, d);
-    hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
     printf("%s:", name);
     for (int i = 0; i < 64; ++i) printf(" %d", h[i]);
     printf("\n");
-    hipFree(d);
+    (void)hipFree(d);
 }
 int main() {
     run<0x130>("wave_shl1");

@@ -1,4 +1,5 @@
-// Unit check of demod_lagsys_kernel against demod_lag3_kernel (same amplitudes, bit for bit) on random data, incl. candidates
+// Unit check of demod_lagsys_kernel against demod_tile_kernel<8, true> (one (symbol, lag) per lane, samples in LDS: the
+// kernel quick mode and WSPR_K4_LAG=tile use) -- same amplitudes, bit for bit -- on random data, incl. candidates
 // that hang over either end of the record.  Includes the kernel file itself (its kernels live in an anonymous namespace).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I rtlsdr-wsprd_amd/csrc/kernels tools/lagsys_check.hip -o tools/lagsys_check.bin
 #include "../rtlsdr-wsprd_amd/csrc/kernels/k4_demod.hip"
@@ -31,8 +32,11 @@ int main(int argc, char** argv) {
     OK(hipMemcpy(dit, items.data(), n * sizeof(FineState), hipMemcpyHostToDevice)); OK(hipMemcpy(dl, list.data(), n * 4, hipMemcpyHostToDevice));
     OK(hipMemset(pa, 0xff, npw * 16)); OK(hipMemset(pb, 0xee, npw * 16));
     hipLaunchKernelGGL(phasor_table_kernel, dim3(1, n), dim3(64), 0, 0, dit, 0, tabs);
-    OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&demod_lag3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kL3Pitch * 8));
-    hipLaunchKernelGGL(demod_lag3_kernel, dim3(kL3Wgs, n), dim3(kL3Threads), (size_t)8 * kL3Pitch * sizeof(float2), 0, dI, dQ, np, dit, dl, tabs, pa);
+    const int span = kSps * kTileSymsShared + 8 * 32, pitch = (span + 7) / 8 + 1;
+    const size_t tile_bytes = (size_t)pitch * 8 * sizeof(float2);
+    const dim3 tile_threads(((kTileSymsShared * 33 + 63) / 64) * 64);
+    hipLaunchKernelGGL((demod_tile_kernel<8, true>), dim3(kNSymD / kTileSymsShared, n), tile_threads, tile_bytes, 0, dI, dQ, np, dit,
+                       dl, 0, 33, 0.0f, tabs, pa);
     hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves + 1, n), dim3(64), 0, 0, dI, dQ, np, dit, dl, n, tabs, pb);
     OK(hipDeviceSynchronize());
     std::vector<float> a(npw * 4), b(npw * 4);
@@ -44,14 +48,14 @@ int main(int argc, char** argv) {
             const size_t o = (((size_t)it * 33 + m) * kNSymD + sy) * 4;
             if (memcmp(&a[o], &b[o], 16)) {
                 ++badi;
-                if (shown++ < 6) printf("  item %d lag %d sym %d (u %d): lag3 %g %g %g %g  lagsys %g %g %g %g\n", it, m, sy, 32 * sy + m,
+                if (shown++ < 6) printf("  item %d lag %d sym %d (u %d): tile %g %g %g %g  lagsys %g %g %g %g\n", it, m, sy, 32 * sy + m,
                                         a[o], a[o+1], a[o+2], a[o+3], b[o], b[o+1], b[o+2], b[o+3]);
             }
         }
         printf("item %d shift %d: %ld of %d differ\n", it, shifts[it], badi, 33 * kNSymD);
         bad += badi;
     }
-    printf(bad ? "MISMATCH\n" : "lagsys == lag3 bit for bit\n");
+    printf(bad ? "MISMATCH\n" : "lagsys == tile kernel bit for bit\n");
     {   // timing on many candidates (the same 8 items repeated)
         const int nb = 2048;
         std::vector<int> big(nb);
@@ -64,13 +68,14 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves + 1, nb), dim3(64), 0, 0, dI, dQ, np, dit, dbl, nb, tabs, pb);
             OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
             float ms; OK(hipEventElapsedTime(&ms, e0, e1));
-            printf("lagsys (EXP %d): %.3f ms per 2048 candidates\n", LAGSYS_EXP, ms / 5);
+            printf("lagsys: %.3f ms per 2048 candidates (two cached segments)\n", ms / 5);
             OK(hipEventRecord(e0, 0));
             for (int k = 0; k < 5; ++k)
-                hipLaunchKernelGGL(demod_lag3_kernel, dim3(kL3Wgs, nb), dim3(kL3Threads), (size_t)8 * kL3Pitch * sizeof(float2), 0, dI, dQ, np, dit, dbl, tabs, pa);
+                hipLaunchKernelGGL((demod_tile_kernel<8, true>), dim3(kNSymD / kTileSymsShared, nb), tile_threads, tile_bytes, 0, dI, dQ,
+                                   np, dit, dbl, 0, 33, 0.0f, tabs, pa);
             OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
             OK(hipEventElapsedTime(&ms, e0, e1));
-            printf("lag3: %.3f ms per 2048 candidates\n", ms / 5);
+            printf("tile kernel: %.3f ms per 2048 candidates\n", ms / 5);
         }
     }
     return bad != 0;
