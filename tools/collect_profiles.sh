@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the summaries of gpurun_out/prof_<round>/ (tools/profile_round.sh) into profiles/ under per-round names.
-R=${1:-r03}; O=gpurun_out/prof_$R; P=profiles
+R=${1:-r04}; O=gpurun_out/prof_$R; P=profiles
 cp $O/default_bench_line.json $P/${R}_default_bench_line.json
 cp $O/default_wall.txt $P/${R}_default_bench_wall_time.txt
 for c in 3 2 5; do
@@ -19,4 +19,5 @@ cp $O/k1_sq.txt $P/${R}_k1_sq_counters.txt
 cp $O/valu_issue_probe.txt $P/${R}_packed_fp32_issue_rate_by_occupancy.txt
 cp $O/k0_cu_share.txt $P/${R}_k0_cu_share_sweep.txt
 cp $O/k0_alone.txt $P/${R}_k0_alone.txt
+for f in insts_by_kernel.txt k0_insts_per_16_bytes.txt k0_alone_process_1.txt k0_in_config5_process.txt k0_in_default_line.txt k0_decoder_overlap_by_residency.txt config5_by_k0_residency.txt kernel_unit_checks.txt; do [ -f $O/$f ] && cp $O/$f $P/${R}_$f; done
 ls -la $P | grep ${R}_

@@ -3,7 +3,7 @@
 # step's vector issue slots go to.  usage (GPU box): tools/insts_by_kernel.sh <outdir>
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=$1; mkdir -p $O
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/raw -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-tertiary --no-pmc --min-seconds 0 --inflight 1 > $O/insts_bench.json 2> $O/insts.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/raw -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-tertiary --no-pmc --no-share-block --no-reference-case --min-seconds 0 --inflight 1 > $O/insts_bench.json 2> $O/insts.err
 python - $(ls $O/raw/*/*counter_collection.csv) > $O/insts_by_kernel.txt <<'PY'
 import csv, sys, collections
 csv.field_size_limit(1 << 30)
