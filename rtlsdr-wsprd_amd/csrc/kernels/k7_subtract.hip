@@ -135,7 +135,7 @@ constexpr int kFirThreads = 256;
 // issued 32 packed multiply/adds per four taps against one 16-byte and four 8-byte LDS reads, and with four SIMDs
 // on one LDS the return path was ~75 % busy: 1.22 vs 0.95 ms per 1024 jobs.)  A lane slides an eight-sample register window (16 packed instructions per 8-byte LDS read) and the taps, the
 // same for every lane, arrive through the scalar cache eight at a time, issued a stage (eight taps = 128
-// packed instructions) before they are needed and waited for when a stage old (see demod_lag3_kernel).  The
+// packed instructions) before they are needed and waited for when a stage old (as the lag scan's table loads).  The
 // tile is stored transposed by 8, so the per-tap read of consecutive lanes is consecutive 8-byte words.
 // Each output is still one serial 360-term sum in tap order: identical bits.
 constexpr int kFir8PerLane = 8;
