@@ -670,10 +670,13 @@ void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__
                          const float* __restrict__ tabs, float4* __restrict__ pw_out) {
     constexpr int nlag = 33;
     const int lane = threadIdx.x;
-    if (blockIdx.x == kSysWaves) {
+    // 1-D grid: first the waves that sum u = 5184 (a candidate per lane: 256 dependent steps of per-lane loads -- at the
+    // front of the grid they run under the bulk; as the last workgroup of every 64th candidate, which a 2-D grid made
+    // them, the final one trailed the launch by ~0.1 ms), then 27 waves per candidate
+    const int nextra = (nitems + 63) >> 6;
+    if ((int)blockIdx.x < nextra) {
         // u = 5184: (symbol 161, lag 32) of 64 candidates, one per lane
-        if (blockIdx.y & 63) return;
-        const int pos = blockIdx.y + lane;
+        const int pos = 64 * (int)blockIdx.x + lane;
         if (pos >= nitems) return;
         const int item = item_list[pos];
         const FineState st = items[item];
@@ -689,11 +692,12 @@ void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__
         pw_out[((size_t)item * nlag + 32) * kNSymD + kNSymD - 1] = a.amplitudes();
         return;
     }
-    const int item = item_list[blockIdx.y];
+    const int w = (int)blockIdx.x - nextra;
+    const int item = item_list[w / kSysWaves];
     const FineState st = items[item];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int u0 = blockIdx.x * kSysU;
+    const int u0 = (w % kSysWaves) * kSysU;
     const int kw = __builtin_amdgcn_readfirstlane(st.shift_coarse - 128 + 8 * u0);
     const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
                                       (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
@@ -1135,8 +1139,8 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
-            hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves + 1, n_shared), dim3(64), 0, st, dI, dQ,      \
-                               samples, items, list_shared, n_shared, tabs, pw4);                                \
+            hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * n_shared + (n_shared + 63) / 64), dim3(64), 0, st, \
+                               dI, dQ, samples, items, list_shared, n_shared, tabs, pw4);                        \
         else if (n_shared > 0)                                                                                   \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \
                                threads(kTileSymsShared), tile_bytes(kTileSymsShared), st, dI, dQ, samples,        \
