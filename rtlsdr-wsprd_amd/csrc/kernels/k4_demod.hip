@@ -521,8 +521,9 @@ void demod_drift_kernel(const float* __restrict__ dI, const float* __restrict__ 
 // No LDS and no barrier: a wave is its own workgroup, occupancy is set by registers alone (the tiled kernel's 57 KB
 // of samples per 256 lanes held it at two waves per SIMD), and the hot loop has no memory instruction that a lane
 // waits for except the table's scalar loads (27 waves of a candidate share the table: scalar-cache hits).
-// Per 8 steps and lane: 8 x 16 x ROWS packed multiplies/adds, 16 DPP moves, 16 uniform loads.
-// u = 5184 (symbol 161 at lag 32) has no lane: one extra workgroup per 64 candidates sums it, a candidate per lane.
+// Per 8 steps and lane: 8 x 16 x ROWS packed multiplies/adds, 16 DPP moves, four uniform 16-byte loads.
+// u = 5184 (symbol 161 at lag 32) has no lane: one extra wave per 64 candidates sums it, a candidate per lane; those
+// waves are the first workgroups of the 1-D grid.
 // Same operations per accumulator as demod_kernel => identical bits.
 constexpr int kSysRows = 3;
 constexpr int kSysU = 64 * kSysRows;                        // outputs per wave
