@@ -658,7 +658,7 @@ def main():
         # ---- the fp32-VALU-bound kernels: tiled lag scan (K4 mode 0), frequency scan + first rung, subtraction (K7)
         vms = (C.c_double * 8)()
         L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
-        if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 3, C.addressof(vms)) > 0 and vms[2] > 0:
+        if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 5, C.addressof(vms)) > 0 and vms[2] > 0:   # five timed passes after an untimed one
             def valu(flop_each, n, t_ms):
                 tf = flop_each * n / (t_ms * 1e-3) / 1e12
                 return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,

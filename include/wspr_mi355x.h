@@ -296,7 +296,7 @@ int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int sa
  * and the fused frequency scan + first ladder rung (wsprd.c:721-758), and one coherent subtraction
  * (K7, wsprd.c:316-413) per segment.  ms must hold 8 doubles: ms[0] = lag scan, ms[1] = subtraction,
  * ms[2] = candidates, ms[3] = subtraction jobs, ms[4] = frequency scan + first rung (milliseconds per
- * launch set). */
+ * launch set, averaged over `iters` passes after one untimed pass, as wspr_bench_fft_sync does). */
 int wspr_bench_valu(const void *d_idat, const void *d_qdat, int nseg, int samples, size_t seg_stride,
                     int iters, double *ms);
 /* Device Fano search (K6w) over n soft-symbol vectors of 162 bytes in transmission
