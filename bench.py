@@ -290,8 +290,18 @@ def reference_case_block(with_cpu):
     """BASELINE configs[0] / the reference's only published metric (README.md:138-151: the decode burst per 2-minute
     segment, 0.5 s on an i7-5820K): ONE wspr_decode() call on the reference's own signal file through the host-buffer
     entry point -- H2D, decode, residual and spots back -- as rtlsdr_wsprd.c:316 calls it once every 120 s."""
-    import oracle_lib as ol
-    I, Q, n = ol.read_iq_file(os.path.join(ROOT, "tests", "golden", "refSignalSnr0dB.iq"))
+    # the product's own reader and print format (rtlsdr_wsprd.c:555-592, 691-701); the oracle is touched by the CPU leg only
+    L = w.lib()
+    I = np.zeros(NS, np.float32)
+    Q = np.zeros(NS, np.float32)
+    n = int(L.wspr_read_iq_file(os.path.join(ROOT, "tests", "golden", "refSignalSnr0dB.iq").encode(),
+                                I.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p)))
+    assert n == NS, "reference signal file not readable"
+
+    def line(spot):
+        buf = C.create_string_buffer(128)
+        L.wspr_format_spot(C.byref(spot), buf, C.c_size_t(128))
+        return buf.value.decode().rstrip("\n")
     opt = w.default_options()
     for _ in range(3):
         spots, _, _ = w.wspr_decode(I, Q, n, opt)
@@ -304,10 +314,11 @@ def reference_case_block(with_cpu):
     blk = {"workload": "configs[0]: signals/refSignalSnr0dB.iq, one wspr_decode() call (host buffers in, residual and "
                        "spots out), warm, median of 20",
            "ms_per_call": 1e3 * times[len(times) // 2], "ms_min": 1e3 * times[0], "ms_max": 1e3 * times[-1],
-           "spots": [ol.spot_line(x) for x in spots],
+           "spots": [line(x) for x in spots],
            "published_reference": {"ms_per_call": 500.0, "hardware": "i7-5820K, one core, FFTW (reference README.md:138-151)",
                                    "note": "context only: other hardware, never a vs_baseline"}}
     if with_cpu:
+        import oracle_lib as ol
         t0 = time.perf_counter()
         for _ in range(5):
             ref, _, _ = ol.decode(I, Q, n)
