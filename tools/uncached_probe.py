@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Does the memory TYPE of the raw rows change how K0 and the decoder share the GPU?  tools/overlap_probe.py with the raw
+segments in (a) ordinary device memory, (b) hipExtMallocWithFlags(hipDeviceMallocUncached), (c) ...Finegrained."""
+import ctypes as C, os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import rtlsdr_wsprd_amd as w
+import bench
+dev = torch.device("cuda", 0)
+L = w.lib()
+hip = C.CDLL("libamdhip64.so")
+nraw, RAW = 32, 576_000_000
+src = torch.randint(1, 256, (nraw, RAW), device=dev, dtype=torch.uint8)
+stride = int(L.wspr_iq_stride())
+rI = torch.zeros(nraw, stride, device=dev); rQ = torch.zeros_like(rI)
+I, Q, _ = bench.synth_batch_gpu(2048, 99, dev, 1, -20.0, -20.0, 1.0)
+L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+L.wspr_bench_decimate.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+torch.cuda.synchronize()
+
+def run(ptr, name):
+    def k0(iters, out):
+        L.wspr_bind_thread_lane(0)
+        ms = (C.c_double * 1)()
+        t = time.perf_counter()
+        L.wspr_bench_decimate(ptr, RAW, nraw, rI.data_ptr(), rQ.data_ptr(), iters, C.addressof(ms))
+        out["k0"] = (time.perf_counter() - t) / iters * 1e3
+    def valu(iters, out):
+        L.wspr_bind_thread_lane(1)
+        ms = (C.c_double * 8)()
+        t = time.perf_counter()
+        L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), 2048, 45000, I.stride(0), iters, C.addressof(ms))
+        out["valu"] = (time.perf_counter() - t) / iters * 1e3
+    for f, n in ((k0, 5), (valu, 3)):
+        o = {}; th = threading.Thread(target=f, args=(n, o)); th.start(); th.join()
+    a = {}; th = threading.Thread(target=k0, args=(40, a)); th.start(); th.join()
+    b = {}; th = threading.Thread(target=valu, args=(20, b)); th.start(); th.join()
+    n0 = max(4, int(round(20 * b["valu"] / a["k0"])))
+    c = {}
+    t0 = time.perf_counter()
+    t1 = threading.Thread(target=k0, args=(n0, c)); t2 = threading.Thread(target=valu, args=(20, c))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    wall = (time.perf_counter() - t0) * 1e3
+    print("%-12s alone: K0 %.3f ms, VALU set %.3f ms | together: K0 %.3f ms, VALU set %.3f ms; wall %.1f ms for %.1f ms back to back" %
+          (name, a["k0"], b["valu"], c["k0"], c["valu"], wall, n0 * a["k0"] + 20 * b["valu"]), flush=True)
+
+run(src.data_ptr(), "default")
+for flag, name in ((3, "uncached"), (1, "finegrained")):
+    p = C.c_void_p()
+    rc = hip.hipExtMallocWithFlags(C.byref(p), C.c_size_t(nraw * RAW), C.c_uint(flag))
+    if rc != 0:
+        print(name, "hipExtMallocWithFlags failed", rc); continue
+    hip.hipMemcpy(p, C.c_void_p(src.data_ptr()), C.c_size_t(nraw * RAW), C.c_int(3))
+    hip.hipDeviceSynchronize()
+    run(p.value, name)
+    hip.hipFree(p)
