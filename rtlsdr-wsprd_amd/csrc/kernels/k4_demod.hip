@@ -693,12 +693,18 @@ void demod_lagsys_kernel(const float* __restrict__ dI, const float* __restrict__
         pw_out[((size_t)item * nlag + 32) * kNSymD + kNSymD - 1] = a.amplitudes();
         return;
     }
+    // XCD-aware placement: consecutive workgroups go to consecutive XCDs (8 of them, each with its own L2), so
+    // workgroup w serves candidate 8 (w / 216) + w % 8, wave (w / 8) % 27: the 27 waves of a candidate -- which share its
+    // 8 KB table and read adjacent, overlapping blocks of its samples -- all run behind ONE L2 (otherwise every XCD
+    // fetches every table); alone the kernel's time does not change, in the pipeline the step gains about 1 %
     const int w = (int)blockIdx.x - nextra;
-    const int item = item_list[w / kSysWaves];
+    const int pos = 8 * (w / (8 * kSysWaves)) + (w & 7);
+    if (pos >= nitems) return;
+    const int item = item_list[pos];
     const FineState st = items[item];
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int u0 = (w % kSysWaves) * kSysU;
+    const int u0 = ((w >> 3) % kSysWaves) * kSysU;
     const int kw = __builtin_amdgcn_readfirstlane(st.shift_coarse - 128 + 8 * u0);
     const float4* __restrict__ gtab = reinterpret_cast<const float4*>(tabs) +
                                       (size_t)__builtin_amdgcn_readfirstlane(st.pad) * 512;
@@ -1140,7 +1146,7 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
-            hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * n_shared + (n_shared + 63) / 64), dim3(64), 0, st, \
+            hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * ((n_shared + 7) & ~7) + (n_shared + 63) / 64), dim3(64), 0, st, \
                                dI, dQ, samples, items, list_shared, n_shared, tabs, pw4);                        \
         else if (n_shared > 0)                                                                                   \
             hipLaunchKernelGGL((demod_tile_kernel<STEP, true>), dim3(kNSymD / kTileSymsShared, n_shared),        \

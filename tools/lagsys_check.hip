@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     const dim3 tile_threads(((kTileSymsShared * 33 + 63) / 64) * 64);
     hipLaunchKernelGGL((demod_tile_kernel<8, true>), dim3(kNSymD / kTileSymsShared, n), tile_threads, tile_bytes, 0, dI, dQ, np, dit,
                        dl, 0, 33, 0.0f, tabs, pa);
-    hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * n + (n + 63) / 64), dim3(64), 0, 0, dI, dQ, np, dit, dl, n, tabs, pb);
+    hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * ((n + 7) & ~7) + (n + 63) / 64), dim3(64), 0, 0, dI, dQ, np, dit, dl, n, tabs, pb);
     OK(hipDeviceSynchronize());
     std::vector<float> a(npw * 4), b(npw * 4);
     OK(hipMemcpy(a.data(), pa, npw * 16, hipMemcpyDeviceToHost)); OK(hipMemcpy(b.data(), pb, npw * 16, hipMemcpyDeviceToHost));
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             OK(hipEventRecord(e0, 0));
             for (int k = 0; k < 5; ++k)
-                hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * nb + (nb + 63) / 64), dim3(64), 0, 0, dI, dQ, np, dit, dbl, nb, tabs, pb);
+                hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * ((nb + 7) & ~7) + (nb + 63) / 64), dim3(64), 0, 0, dI, dQ, np, dit, dbl, nb, tabs, pb);
             OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
             float ms; OK(hipEventElapsedTime(&ms, e0, e1));
             printf("lagsys: %.3f ms per 2048 candidates (two cached segments)\n", ms / 5);
