@@ -164,6 +164,9 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
     __shared__ float2 rref[kFir8Out];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
+    // staging (loads, sincos: short dependent chains that want to issue at once) runs at a higher wave priority than the
+    // FIR loop, which fills whatever issue slots are left: 2.58 -> 2.50 ms per 2 048 jobs
+    __builtin_amdgcn_s_setprio(3);
     const SubJob* job = jobs + blockIdx.y;
     const PhaseTable& tb = tables[blockIdx.y];
     const bool dense = tb.first_run[0] == 0xffffu;
@@ -278,6 +281,7 @@ void sub_fir_fused_kernel(float* __restrict__ dI, float* __restrict__ dQ, int np
             for (int r = 0; r < 8; ++r) acc[r] = acc[r] + p[r];
         }
     };
+    __builtin_amdgcn_s_setprio(0);
     issue(W[1], Ta[0], Tb[0], 0);
     static_assert(kLpfTaps % 24 == 0, "three stages of eight taps per trip");
 #pragma unroll 1
