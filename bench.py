@@ -340,6 +340,8 @@ def share_of_8_block(args, inflight):
            "--inflight", str(inflight)]
     if args.segments:
         cmd += ["--segments", str(args.segments)]
+    if args.slots:
+        cmd += ["--slots", str(args.slots)]
     import subprocess
     t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -409,8 +411,11 @@ def main():
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight (default: 6 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
+                    help="batches in flight (default: 12 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
+    ap.add_argument("--slots", type=int, default=None,
+                    help="concurrent pipelines per batch inside the library (wspr_set_thread_slots; default: 1 for --config 3, "
+                         "where the batches in flight already overlap each other, else the library's own 3)")
     ap.add_argument("--spawn", action="store_true",
                     help="take the launcher path even for --gpus 1 (one rank under torch.distributed.run with the RCCL "
                          "process group, broadcast and gather): how the multi-GPU entry is exercised on a 1-GPU box")
@@ -456,6 +461,7 @@ def main():
     distinct_devices = len(set(devs))
     L = w.lib()
     L.wspr_set_fano_fast_budget.restype = C.c_uint
+    L.wspr_release_buffers.restype = C.c_size_t
     if args.k0_cus is not None:
         L.wspr_set_front_end_cus(args.k0_cus)
 
@@ -465,11 +471,13 @@ def main():
     cpus_here = int(os.environ["WSPR_HOST_THREADS"])
     # crowded band (configs[2]): the Fano attempts run on the device (library default for such batches), the host
     # only keeps books, and several batches in flight cover the device round trips of a wave (round 2: 25.5 / 25.9 /
-    # 27.2 k segments/s with 2 / 3 / 4 in flight; round 3: 30.7 / 31.8 / 30.9 k with 4 / 6 / 8); otherwise two if the
-    # rank has the CPUs
-    inflight = args.inflight if args.inflight else (6 if args.config == 3 else
+    # 27.2 k segments/s with 2 / 3 / 4 in flight; round 3: 30.7 / 31.8 / 30.9 k with 4 / 6 / 8, three slots each; round 4:
+    # ONE slot per batch -- every kernel launch covers the whole batch -- and twelve batches in flight: 231-233 ms per
+    # step with 3 slots x 6, 226-230 with 1 x 8, 220-224 with 1 x 12, 221-225 with 1 x 16, one box); otherwise two if
+    # the rank has the CPUs
+    inflight = args.inflight if args.inflight else (12 if args.config == 3 else
                                                    (3 if args.config == 2 and cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
-    inflight = max(1, min(inflight, 8))
+    inflight = max(1, min(inflight, 16))
     from concurrent.futures import ThreadPoolExecutor
     lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
 
@@ -485,9 +493,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lanes_primary = inflight
+
     def measure(config, nseg, steps, warmup, seed):
         """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds)."""
         fast_old = None
+        # the other configurations' blocks keep the six in flight their round-3 figures were taken with (configs[4]
+        # holds 147 GB of raw data resident: twelve IQ rings beside it do not fit)
+        inflight = lanes_primary if config == args.config else min(lanes_primary, 6)
         if config == 2:
             I, Q, expected = synth_batch_gpu(nseg, 1234 + seed, dev, 1, args.snr, args.snr, 1.0)
             workload = "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr)
@@ -521,6 +534,8 @@ def main():
                         "call; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's 4096 segments = %d such steps"
                         % (nraw, nraw, nseg, args.snr, max(1, 4096 // nseg)))
         torch.cuda.synchronize()
+        slots = args.slots if args.slots else (1 if config == 3 else 0)
+        slots_used = [ex.submit(L.wspr_set_thread_slots, slots).result() for ex in lanes][0]
         decs = [w.BatchDecoder(nseg, max_results=16 if config != 3 else 32, options=opt) for _ in range(inflight)]
         gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
         if config == 5:                                  # the decimator's output rows, one set per lane
@@ -593,7 +608,7 @@ def main():
         if fast_old is not None:
             L.wspr_set_fano_fast_budget(C.c_uint(fast_old))
         return {"config": config, "nseg": nseg, "I": I, "Q": Q, "raw": raw, "expected": expected, "got": got,
-                "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed,
+                "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed, "slots": slots_used,
                 "value": world * nseg * n_timed / elapsed, "ms_per_step": elapsed / n_timed * 1e3,
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
                 "timings": timings}
@@ -733,6 +748,7 @@ def main():
             del I, Q
             m["I"] = m["Q"] = None
             torch.cuda.empty_cache()
+            released = L.wspr_release_buffers()          # the twelve lanes' work buffers of the 8192-segment batches
             m2 = measure(2, 1024, 200, 8, rank)
             secondary = {"workload": m2["workload"], "value": m2["value"], "unit": "segments/s", "steps": m2["steps"],
                          "ms_per_step": m2["ms_per_step"], "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
@@ -743,6 +759,7 @@ def main():
             # throughput, K0's roofline and the decimator's CPU baseline
             m["I"] = m["Q"] = None
             torch.cuda.empty_cache()
+            L.wspr_release_buffers()
             m3 = measure(5, 1024, 6, 2, rank)
             tertiary = {"workload": m3["workload"], "value": m3["value"], "unit": "segments/s", "steps": m3["steps"],
                         "ms_per_step": m3["ms_per_step"], "seconds_timed": m3["elapsed"], "decoded_ok": m3["decoded_ok"],
@@ -762,7 +779,7 @@ def main():
                        "gathered_over": ("rccl" if backend == "nccl" else backend) if use_dist else "none (one process)",
                        "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("WSPR_BENCH_SPAWNED")
                        else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
-                       "batches_in_flight": inflight, "untimed_steps": m["untimed"]},
+                       "batches_in_flight": inflight, "slots_per_batch": m["slots"], "untimed_steps": m["untimed"]},
             "steps_requested": args.steps, "seconds_timed": m["elapsed"], "first_try": m["first_try"],
             "decoded_ok": m["decoded_ok"], "false_decodes": m["false_decodes"], "spots_total": m["spots_total"],
             "stage_ms_last_step": dict(m["timings"], note="times: maximum over the slots of the lane that ran the last "
@@ -778,6 +795,7 @@ def main():
                 out["reference_case_configs0"] = reference_case_block(not args.no_cpu_baseline)
             if not args.no_share_block:
                 torch.cuda.empty_cache()
+                L.wspr_release_buffers()
                 out["per_rank_share_of_8"] = share_of_8_block(args, inflight)
     line = json.dumps(out) if rank == 0 else None
     if use_dist:

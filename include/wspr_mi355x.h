@@ -315,11 +315,22 @@ int wspr_fano_batch_device_wave(const unsigned char *symbols, int n, unsigned ma
  * involved. */
 int wspr_device_count(void);
 int wspr_set_device(int device);
-/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to eight
+/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to sixteen
  * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
- * this (returns the lane actually bound, 0..7; a ninth lane is reserved for receiver sessions); calls made from
+ * this (returns the lane actually bound, 0..15; one more lane is reserved for receiver sessions); calls made from
  * threads bound to different lanes may overlap, e.g. to start the next batch under the tail of the current one. */
 int wspr_bind_thread_lane(int lane);
+/* A batch of >= 128 segments is split over up to WSPR_SLOTS (default 3) concurrent pipelines ("slots") of the
+ * calling thread's lane, so that one call overlaps its own host phases with its own kernels.  A service that
+ * already keeps several batches in flight on different lanes gets that overlap from the lanes: this caps the
+ * slots of the calling thread's later calls at n (n <= 0: no cap) and returns the number they will use. */
+int wspr_set_thread_slots(int n);
+/* Memory.  The library keeps the work buffers of every (device, lane, slot) it has used, sized for the largest
+ * batch seen there (about 1 MB of HBM per segment).  This returns the work buffers of the CURRENT device -- all
+ * lanes, device and pinned host memory -- to the driver and reports the device bytes freed; tables, streams and
+ * host pools stay, and the next call allocates what it needs.  No other call of the library may be in flight on
+ * that device.  Nothing a caller can observe lives in these buffers between calls. */
+size_t wspr_release_buffers(void);
 /* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
  * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with
  * the reference's 10000, and a segment in which one of those decodes after all is decoded again with

@@ -564,6 +564,20 @@ int wspr_bind_thread_lane(int lane) {
     return Context::lane();
 }
 
+int wspr_set_thread_slots(int n) {
+    Context::cap_slots(n <= 0 ? 8 : n);
+    return Context::slot_cap();
+}
+
+size_t wspr_release_buffers(void) {
+    try {
+        return Context::release_buffers();
+    } catch (const std::exception& e) {
+        fprintf(stderr, "libwspr_mi355x: wspr_release_buffers failed: %s\n", e.what());
+        return 0;
+    }
+}
+
 unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
     return wspr::fano_fast_budget().exchange(cycles_per_bit);
 }

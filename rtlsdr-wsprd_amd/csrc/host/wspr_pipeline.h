@@ -54,12 +54,13 @@ public:
     static Context& get();          // slot 0; throws std::runtime_error when no HIP device is usable
     static Context& slot(int i);    // i in [0, slots())
     static int slots();             // concurrent pipelines per process (env WSPR_SLOTS, default 3)
-    static constexpr int kMaxLanes = 9;          // lanes 0..7 for callers, the last one for receiver sessions (feed)
+    static constexpr int kMaxLanes = 17;         // lanes 0..15 for callers, the last one for receiver sessions (feed)
     static constexpr int kUserLanes = kMaxLanes - 1;
     static constexpr int kMaxDevices = 16;
     static int lane();              // lane of the calling thread
     static void bind_lane(int lane);
     static void cap_slots(int n);   // calling thread: use at most n slots per batch (a shard's share of the host)
+    static size_t release_buffers();   // current device, every lane and slot: bytes of device memory returned
     static int slot_cap();          // min(slots(), the thread's cap, the CPUs of its share)
     int device();
     ~Context();

@@ -53,6 +53,13 @@ struct DevBuf {
         }
         return p;
     }
+    size_t release() {
+        const size_t had = cap;
+        if (p) HIP_OK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        return had;
+    }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 struct PinBuf {
@@ -67,6 +74,11 @@ struct PinBuf {
             cap = want;
         }
         return p;
+    }
+    void release() {
+        if (p) HIP_OK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
     }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
@@ -327,9 +339,12 @@ void Context::bind_lane(int lane) { t_lane = std::max(0, std::min(lane, kMaxLane
 
 // Contexts are kept per (device, lane, slot): a host thread decodes on the HIP device that is current for it
 // (hipSetDevice / wspr_set_device), so one process can drive every GPU of a node, one thread (or more) each.
+static std::mutex g_ctx_mutex;
+static std::unique_ptr<Context> g_ctx[Context::kMaxDevices][Context::kMaxLanes][8];
+
 Context& Context::slot(int i) {
-    static std::mutex m;
-    static std::unique_ptr<Context> ctx[kMaxDevices][kMaxLanes][8];
+    std::mutex& m = g_ctx_mutex;
+    auto& ctx = g_ctx;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess)
         throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
@@ -341,6 +356,33 @@ Context& Context::slot(int i) {
 }
 
 Context& Context::get() { return slot(0); }
+
+// Work buffers (device and pinned) of every context of the current device go back to the driver; the constant
+// tables, streams and host pools stay, the next call allocates what it needs.  No call may be in flight.
+size_t Context::release_buffers() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    std::lock_guard<std::mutex> g(g_ctx_mutex);
+    size_t freed = 0;
+    for (int lane = 0; lane < kMaxLanes; ++lane)
+        for (int i = 0; i < 8; ++i) {
+            if (!g_ctx[dev][lane][i]) continue;
+            Impl& c = *g_ctx[dev][lane][i]->d;
+            HIP_OK(hipStreamSynchronize(c.stream));
+            for (DevBuf* b : {&c.iqI, &c.iqQ, &c.ps, &c.cand, &c.npk, &c.noise, &c.smspec, &c.seglist, &c.items, &c.syncbuf,
+                              &c.symbuf, &c.rmsbuf, &c.jobs, &c.subscratch, &c.nvalid, &c.decscratch, &c.tabs, &c.pw, &c.pwfreq,
+                              &c.lists, &c.scrsync, &c.psavg, &c.fz_sym, &c.fz_off, &c.fz_ret, &c.fz_cyc, &c.fz_met, &c.fz_max,
+                              &c.fz_dat, &c.fz_steps, &c.fz_pool, &c.streamraw, &c.streamstate})
+                freed += b->release();
+            for (PinBuf* b : {&c.h_npk, &c.h_cand, &c.h_items, &c.h_sync, &c.h_sym, &c.h_rms, &c.h_jobs, &c.h_jobs2, &c.h_seglist,
+                              &c.h_misc, &c.h_lists})
+                b->release();
+            free(c.hash_arena);
+            c.hash_arena = nullptr;
+            c.hash_arena_segs = 0;
+        }
+    return freed;
+}
 
 int Context::device() { return d->device; }
 

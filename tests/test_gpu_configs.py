@@ -355,7 +355,7 @@ def test_receiver_session_rollover_during_a_feed(env):
     L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.wspr_session_samples.restype = C.POINTER(C.c_float)
     L.wspr_session_destroy.argtypes = [C.c_void_p]
-    assert L.wspr_bind_thread_lane(11) == 7 and L.wspr_bind_thread_lane(0) == 0      # lane 8 is the sessions'
+    assert L.wspr_bind_thread_lane(21) == 15 and L.wspr_bind_thread_lane(0) == 0     # lane 16 is the sessions'
     CB, NCB = 65536, 600
     rng = np.random.default_rng(99)
     host = rng.integers(0, 256, CB * NCB, dtype=np.uint8)

@@ -227,6 +227,54 @@ def test_two_lanes_decode_concurrently_and_identically(env):
         assert all(r == solo[k] for r in out[k]), k
 
 
+def test_slot_cap_of_a_thread_changes_nothing_but_the_split(env):
+    """wspr_set_thread_slots(): a thread's batches run as one pipeline instead of three; the spots are the same,
+    and lanes 8..15 exist (a service with many batches in flight and one slot each)."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch, bench, w, dev = env
+    nseg = 390
+    L = w.lib()
+    I, Q = bench.synth_batch_gpu(nseg, 77, dev, 3, -15.0, -26.0, 0.4)[:2]
+    d = w.BatchDecoder(nseg, 16)
+    d.decode(I, Q)
+    three = [[_tup(x) for x in d.spots(s)] for s in range(nseg)]
+    assert sum(len(x) for x in three) > nseg
+
+    def worker(lane):
+        torch.cuda.set_device(0)
+        assert L.wspr_bind_thread_lane(lane) == lane
+        assert L.wspr_set_thread_slots(1) == 1
+        dd = w.BatchDecoder(nseg, 16)
+        dd.decode(I, Q)
+        got = [[_tup(x) for x in dd.spots(s)] for s in range(nseg)]
+        assert L.wspr_set_thread_slots(0) >= 1
+        return got
+    with ThreadPoolExecutor(2) as ex:
+        out = [f.result() for f in [ex.submit(worker, lane) for lane in (9, 15)]]
+    assert out[0] == three and out[1] == three
+
+
+def test_release_buffers_gives_the_memory_back_and_changes_nothing(env):
+    """wspr_release_buffers(): the work buffers of every lane go back to the driver; the next decode allocates
+    again and reports the same spots."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_release_buffers.restype = C.c_size_t
+    nseg = 512
+    I, Q = bench.synth_batch_gpu(nseg, 78, dev, 2, -15.0, -25.0, 0.4)[:2]
+    d = w.BatchDecoder(nseg, 16)
+    d.decode(I, Q)
+    before = [[_tup(x) for x in d.spots(s)] for s in range(nseg)]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    freed = L.wspr_release_buffers()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert freed > nseg * 500_000 and free1 - free0 >= freed // 2
+    assert L.wspr_release_buffers() == 0
+    d.decode(I, Q)
+    assert [[_tup(x) for x in d.spots(s)] for s in range(nseg)] == before
+
+
 def test_two_lanes_with_fano_split_and_memo(env):
     """Both lanes at once, each on a crowded batch with a 40 cycles/bit host Fano budget: device tails,
     re-decodes and their memos run concurrently and every lane still reports the exact schedule's spots."""
