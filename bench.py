@@ -411,11 +411,11 @@ def main():
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight (default: 12 for --config 3, 3 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1): step k+1 starts "
+                    help="batches in flight (default: 12 for --config 3, 12 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1; 6 for --config 5): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
     ap.add_argument("--slots", type=int, default=None,
-                    help="concurrent pipelines per batch inside the library (wspr_set_thread_slots; default: 1 for --config 3, "
-                         "where the batches in flight already overlap each other, else the library's own 3)")
+                    help="concurrent pipelines per batch inside the library (wspr_set_thread_slots; default: 1 with four or more "
+                         "batches in flight -- they already overlap each other -- else the library's own 3)")
     ap.add_argument("--spawn", action="store_true",
                     help="take the launcher path even for --gpus 1 (one rank under torch.distributed.run with the RCCL "
                          "process group, broadcast and gather): how the multi-GPU entry is exercised on a 1-GPU box")
@@ -473,13 +473,15 @@ def main():
     # only keeps books, and several batches in flight cover the device round trips of a wave (round 2: 25.5 / 25.9 /
     # 27.2 k segments/s with 2 / 3 / 4 in flight; round 3: 30.7 / 31.8 / 30.9 k with 4 / 6 / 8, three slots each; round 4:
     # ONE slot per batch -- every kernel launch covers the whole batch -- and twelve batches in flight: 231-233 ms per
-    # step with 3 slots x 6, 226-230 with 1 x 8, 220-224 with 1 x 12, 221-225 with 1 x 16, one box); otherwise two if
-    # the rank has the CPUs
-    inflight = args.inflight if args.inflight else (12 if args.config == 3 else
-                                                   (3 if args.config == 2 and cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
-    inflight = max(1, min(inflight, 16))
+    # step with 3 slots x 6, 226-230 with 1 x 8, 220-224 with 1 x 12, 221-225 with 1 x 16, one box).  configs[1] the
+    # same way: 3.93 ms per 1 024 segments with 3 slots x 3, 3.55-3.65 with 2 x 4, 3.26-3.31 with 1 x 6 or 8,
+    # 3.19-3.24 with 1 x 12.  configs[4] does not care (197-201 ms with 3 x 6 or 1 x 6) and holds 147 GB of raw data
+    # resident, so it stays at six.  With few CPUs per rank: two in flight, or one.
+    def default_inflight(config):
+        return 12 if config == 3 else (6 if config == 5 else (12 if cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
+    inflight = max(1, min(args.inflight if args.inflight else default_inflight(args.config), 16))
     from concurrent.futures import ThreadPoolExecutor
-    lanes = [ThreadPoolExecutor(1) for _ in range(inflight)]
+    lanes = [ThreadPoolExecutor(1) for _ in range(16 if not args.inflight else inflight)]
 
     def bind(lane):
         torch.cuda.set_device(local)
@@ -498,9 +500,7 @@ def main():
     def measure(config, nseg, steps, warmup, seed):
         """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds)."""
         fast_old = None
-        # the other configurations' blocks keep the six in flight their round-3 figures were taken with (configs[4]
-        # holds 147 GB of raw data resident: twelve IQ rings beside it do not fit)
-        inflight = lanes_primary if config == args.config else min(lanes_primary, 6)
+        inflight = lanes_primary if config == args.config else (min(args.inflight, 6) if args.inflight else default_inflight(config))
         if config == 2:
             I, Q, expected = synth_batch_gpu(nseg, 1234 + seed, dev, 1, args.snr, args.snr, 1.0)
             workload = "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr)
@@ -534,7 +534,7 @@ def main():
                         "call; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's 4096 segments = %d such steps"
                         % (nraw, nraw, nseg, args.snr, max(1, 4096 // nseg)))
         torch.cuda.synchronize()
-        slots = args.slots if args.slots else (1 if config == 3 else 0)
+        slots = args.slots if args.slots else (1 if inflight >= 4 else 0)         # few in flight: the library's own split
         slots_used = [ex.submit(L.wspr_set_thread_slots, slots).result() for ex in lanes][0]
         decs = [w.BatchDecoder(nseg, max_results=16 if config != 3 else 32, options=opt) for _ in range(inflight)]
         gatherers = [wd.SpotGatherer(d.out, d.nres, nseg, d.max_results, rec, dst=0) for d in decs] if use_dist else None
@@ -608,7 +608,7 @@ def main():
         if fast_old is not None:
             L.wspr_set_fano_fast_budget(C.c_uint(fast_old))
         return {"config": config, "nseg": nseg, "I": I, "Q": Q, "raw": raw, "expected": expected, "got": got,
-                "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed, "slots": slots_used,
+                "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed, "slots": slots_used, "inflight": inflight,
                 "value": world * nseg * n_timed / elapsed, "ms_per_step": elapsed / n_timed * 1e3,
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
                 "timings": timings}
@@ -751,7 +751,8 @@ def main():
             released = L.wspr_release_buffers()          # the twelve lanes' work buffers of the 8192-segment batches
             m2 = measure(2, 1024, 200, 8, rank)
             secondary = {"workload": m2["workload"], "value": m2["value"], "unit": "segments/s", "steps": m2["steps"],
-                         "ms_per_step": m2["ms_per_step"], "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
+                         "ms_per_step": m2["ms_per_step"], "batches_in_flight": m2["inflight"], "slots_per_batch": m2["slots"],
+                         "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
                          "false_decodes": m2["false_decodes"], "stage_ms_last_step": m2["timings"]}
         tertiary = None
         if world == 1 and args.config == 3 and not args.no_tertiary and not use_dist:
@@ -762,7 +763,8 @@ def main():
             L.wspr_release_buffers()
             m3 = measure(5, 1024, 6, 2, rank)
             tertiary = {"workload": m3["workload"], "value": m3["value"], "unit": "segments/s", "steps": m3["steps"],
-                        "ms_per_step": m3["ms_per_step"], "seconds_timed": m3["elapsed"], "decoded_ok": m3["decoded_ok"],
+                        "ms_per_step": m3["ms_per_step"], "batches_in_flight": m3["inflight"], "slots_per_batch": m3["slots"],
+                        "seconds_timed": m3["elapsed"], "decoded_ok": m3["decoded_ok"],
                         "false_decodes": m3["false_decodes"], "stage_ms_last_step": m3["timings"],
                         "front_end_K0": k0_report(L, m3, not args.no_cpu_baseline)}
             del m3
