@@ -818,14 +818,17 @@ constexpr int kFsThreads = 832;                                   // 13 waves: 5
 constexpr int kFsChunk = 32;
 constexpr int kFsPerThread = (kNSymD * kFsChunk + kFsThreads - 1) / kFsThreads;      // 7 samples staged per thread and chunk
 
-// Scalar-table form of freq_tile_kernel: a hypothesis owns three whole waves (lane = symbol, 162 of 192 lanes),
-// so its one table is wave-uniform and is read through the scalar cache straight into SGPR operands of the packed
-// multiplies, as in the lag scan -- no 40 KB of tables in LDS (three workgroups per CU instead of one) and no
-// two 16-byte LDS reads per lane and step.
-constexpr int kFqThreads = 960;                                   // 5 hypotheses x 3 waves
-constexpr int kFqPerThread = (kNSymD * kFsChunk + kFqThreads - 1) / kFqThreads;      // 6 samples staged per thread and chunk
+// Scalar-table frequency scan: a hypothesis owns three whole waves (lane = symbol, 162 of 192 lanes), so its one
+// table is wave-uniform and is read through the scalar cache straight into SGPR operands of the packed multiplies,
+// as in the lag scan -- no 40 KB of tables in LDS and no two 16-byte LDS reads per lane and step.  The centre
+// hypothesis is not summed: the lag scan has formed exactly these sums for the lag that won (centre_from_lag_scan),
+// so twelve waves sum the other four and the first three copy the centre's amplitudes (round 4; until then the
+// centre had three waves of its own that only helped staging).  A candidate whose state is not a grid point of the
+// lag scan (no lag won) gets its centre from freq_centre_rare_kernel behind this one.
+constexpr int kFqThreads = 768;                                   // 4 hypotheses x 3 waves
+constexpr int kFqPerThread = (kNSymD * kFsChunk + kFqThreads - 1) / kFqThreads;      // 7 samples staged per thread and chunk
 
-__global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(6, 8), amdgpu_num_vgpr(64)))
 void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                         const FineState* __restrict__ items, const int* __restrict__ item_list,
                         const float* __restrict__ tabs, float4* __restrict__ pw_out,
@@ -837,10 +840,10 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
     const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
     const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = wave / 3, sym = (wave - 3 * f) * 64 + (tid & 63);
-    // the centre hypothesis' three waves only help staging when the lag scan holds its amplitudes
-    const int m_centre = (f == kNFreq / 2) ? centre_from_lag_scan(st, pw_lag ? nlag : 0, lagstep) : -1;
-    const bool working = sym < kNSymD && m_centre < 0;
+    const int h = wave / 3, sym = (wave - 3 * h) * 64 + (tid & 63);
+    const int f = h < kNFreq / 2 ? h : h + 1;
+    const int m_centre = centre_from_lag_scan(st, nlag, lagstep);          // block-uniform
+    const bool working = sym < kNSymD;
     const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps);
 
     float2 nxt[kFqPerThread];
@@ -874,7 +877,33 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
         }
     }
     if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
-    else if (sym < kNSymD) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
+    if (m_centre >= 0 && h == 0 && working)
+        pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
+}
+
+// The centre hypothesis of the candidates freq_scalar_kernel could not copy it for (rare: no lag won; or nlag = 0,
+// the WSPR_K4_FREQ=nocentre switch of the trace tests): one wave per candidate checks, and sums the 162 symbols
+// itself, three rounds of 64, samples straight from memory -- the same operations in the same order.
+__global__ __launch_bounds__(64)
+void freq_centre_rare_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
+                             const FineState* __restrict__ items, const int* __restrict__ item_list,
+                             const float* __restrict__ tabs, float4* __restrict__ pw_out, int nlag, int lagstep) {
+    const int slot = blockIdx.x;
+    const FineState st = items[item_list[slot]];
+    if (centre_from_lag_scan(st, nlag, lagstep) >= 0) return;
+    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
+    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
+    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + kNFreq / 2) * (2 * kSps);
+    for (int sym = threadIdx.x; sym < kNSymD; sym += 64) {
+        ToneAcc acc;
+        acc.clear();
+        for (int j = 0; j < kSps; ++j) {
+            const int k = st.shift + kSps * sym + j;
+            const bool ok = (k > 0) && (k < np);
+            acc.step(ok ? make_float2(xi[k], xq[k]) : make_float2(0.0f, 0.0f), gt[2 * j], gt[2 * j + 1]);
+        }
+        pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = acc.amplitudes();
+    }
 }
 
 // The same scan for a DRIFTING candidate: every (hypothesis, symbol) has its own four tone phasors and each
@@ -1089,10 +1118,19 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     // pw_lag (optional): the lag scan's amplitude block [item][nlag_lag][162] of the SAME items, still intact --
     // the centre hypothesis is read from it instead of being summed again; pw must then be a different buffer
     const float4* pl = reinterpret_cast<const float4*>(pw_lag);
+    // WSPR_REPEAT_FREQ / _LAG / _FANO = 2: the stage's kernels are launched twice (same outputs) -- what a stage costs
+    // INSIDE the pipelined step is the difference of two bench lines
+    static const int rep_freq = [] { const char* e = getenv("WSPR_REPEAT_FREQ"); return e ? atoi(e) : 1; }();
+    // WSPR_K4_FREQ=nocentre: no centre hypothesis is taken from the lag scan (every candidate through the rare path)
+    static const bool nocentre = [] { const char* e = getenv("WSPR_K4_FREQ"); return e && e[0] == 'n'; }();
+    const int nlag_c = (pl && !nocentre) ? nlag_lag : 0;
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-        hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
-                           list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_lag, lagstep);
+        for (int r = 0; r < rep_freq; ++r)
+            hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
+                               list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
+        hipLaunchKernelGGL(freq_centre_rare_kernel, dim3(n_shared), dim3(64), 0, st, dI, dQ, samples, items, list_shared,
+                           tabs, reinterpret_cast<float4*>(pw), nlag_c, lagstep);
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
                            reinterpret_cast<const float4*>(pw), items, list_shared, n_shared, -2, 0.1f, minsync1,
                            sync_out, sym_out, rms_out, t.sync);
@@ -1102,8 +1140,9 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
         if (!general) {
             // pw rows of the drifting candidates follow those of the drift-free ones
             float4* pw_own = reinterpret_cast<float4*>(pw) + (size_t)n_shared * kNFreq * kNSymD;
+            for (int r = 0; r < rep_freq; ++r)
             hipLaunchKernelGGL(freq_drift_kernel, dim3(n_own), dim3(kFsThreads), 0, st, dI, dQ, samples, items, list_own,
-                               -2, 0.1f, pw_own, pl, nlag_lag, lagstep);
+                               -2, 0.1f, pw_own, nocentre ? nullptr : pl, nlag_lag, lagstep);
             hipLaunchKernelGGL(freq_metric_kernel, dim3(n_own), dim3(64), 0, st, pw_own, items, list_own, n_own, -2, 0.1f,
                                minsync1, sync_out, sym_out, rms_out, t.sync);
             return;
@@ -1143,9 +1182,11 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     static const bool lagsys_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
     static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
+    static const int rep_lag = [] { const char* e = getenv("WSPR_REPEAT_LAG"); return e ? atoi(e) : 1; }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
+            for (int r_ = 0; r_ < rep_lag; ++r_)                                                                 \
             hipLaunchKernelGGL(demod_lagsys_kernel, dim3(kSysWaves * ((n_shared + 7) & ~7) + (n_shared + 63) / 64), dim3(64), 0, st, \
                                dI, dQ, samples, items, list_shared, n_shared, tabs, pw4);                        \
         else if (n_shared > 0)                                                                                   \
@@ -1153,6 +1194,7 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                                threads(kTileSymsShared), tile_bytes(kTileSymsShared), st, dI, dQ, samples,        \
                                items, list_shared, mode, nlag, minsync1, tabs, pw4);                             \
         if (n_own > 0 && STEP == 8 && nlag == 33 && mode == 0 && drift_kernel)                                   \
+            for (int r_ = 0; r_ < rep_lag; ++r_)                                                                 \
             hipLaunchKernelGGL(demod_drift_kernel, dim3((kNSymD + kDrSyms - 1) / kDrSyms, n_own), dim3(64), 0, st, \
                                dI, dQ, samples, items, list_own, pw4);                                           \
         else if (n_own > 0)                                                                                      \

@@ -58,7 +58,8 @@ def _run_with(env, sets):
     assert r.returncode == 0 and "TRACE PARITY OK" in r.stdout, (env, r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env", [{"WSPR_K4_LAG": "tile"}, {"WSPR_K4_DRIFT": "tile"}, {"WSPR_FANO_DEVICE": "1"},
+@pytest.mark.parametrize("env", [{"WSPR_K4_LAG": "tile"}, {"WSPR_K4_DRIFT": "tile"}, {"WSPR_K4_FREQ": "nocentre"},
+                                 {"WSPR_FANO_DEVICE": "1"},
                                  {"WSPR_FANO_DEVICE": "0"}, {"WSPR_K3_KERNEL": "lane", "WSPR_K1_FUSED": "1"},
                                  {"WSPR_K3_KERNEL": "waves", "WSPR_K1_FUSED": "0", "WSPR_SLOTS": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
