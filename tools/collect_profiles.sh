@@ -8,7 +8,7 @@ for c in 3 2 5; do
   cp $O/c${c}_kernel_by_grid.csv $P/${R}_config${c}_kernel_by_grid.csv
   grep '^{' $O/c${c}_bench.json | tail -1 > $P/${R}_config${c}_bench_under_rocprof.json
 done
-cp $O/c3_gpu_busy.txt $P/${R}_config3_gpu_busy.txt
+cp $O/c3_gpu_busy.txt $P/${R}_config3_gpu_busy.txt; cp $O/c2_gpu_busy.txt $P/${R}_config2_gpu_busy.txt
 cp $O/sq_c3_summary.json $P/${R}_config3_sq_counters.json
 cp $O/k1_pmc_traffic_8192.json $P/${R}_k1_pmc_traffic.json
 cp $O/k1_pmc_traffic_1024.json $P/${R}_k1_pmc_traffic_1024seg.json

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 R=${1:-r04}; O=gpurun_out/prof_$R; mkdir -p $O
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/default_bench_line.json 2> $O/default.err ) 2> $O/default_wall.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python bench.py --steps 24 --warmup 2 --no-ceilings --no-cpu-baseline --no-secondary --no-tertiary --no-pmc --no-share-block --no-reference-case --min-seconds 0 > $O/c3_bench.json 2> $O/c3.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python bench.py --config 2 --steps 100 --no-cpu-baseline --no-pmc --min-seconds 0 > $O/c2_bench.json 2> $O/c2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python bench.py --config 2 --steps 300 --no-cpu-baseline --no-pmc --no-ceilings --min-seconds 0 > $O/c2_bench.json 2> $O/c2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python bench.py --config 5 --segments 512 --steps 3 --warmup 1 --no-cpu-baseline --min-seconds 0 > $O/c5_bench.json 2> $O/c5.err
 for cfg in "8192 10" "1024 1"; do set -- $cfg
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_$1 -- python tools/pmc_k1.py $1 $2 > $O/fetch_$1.log 2>&1
@@ -19,6 +19,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python tools/sq_summarise.py $(ls $O/sq_c3/*/*counter_collection.csv) > $O/sq_c3_summary.json
 for c in c3 c2 c5; do python tools/profile_summary.py $(ls $O/$c/*/*kernel_trace.csv) > $O/${c}_kernel_by_grid.csv; cp $(ls $O/$c/*/*kernel_stats.csv) $O/${c}_kernel_stats.csv; done
 python tools/gpu_busy.py $(ls $O/c3/*/*kernel_trace.csv) 0.6 0.95 > $O/c3_gpu_busy.txt 2>&1
+python tools/gpu_busy.py $(ls $O/c2/*/*kernel_trace.csv) 0.45 0.9 > $O/c2_gpu_busy.txt 2>&1
 # isolated launch sets: per-kernel durations and SQ counters (2 048 single-signal candidates)
 tools/kprobe.sh $O/isolated 2048 1 > $O/isolated_kernels.txt 2>&1
 tools/sqprobe.sh $O/isolated_sq 2048 1 > $O/isolated_sq.txt 2>&1
