@@ -65,10 +65,10 @@ def test_config3_8192_segments_x_10_signals(env):
     h = w.BatchDecoder(nseg // 2, 32)
     h.decode(I[: nseg // 2].contiguous(), Q[: nseg // 2].contiguous())
     assert [[_tup(x) for x in h.spots(s)] for s in range(nseg // 2)] == full[: nseg // 2]
-    # exact agreement with the CPU oracle on 128 sampled segments (all fields of all spots, in order); a longer
-    # soak: WSPR_CONFIG3_ORACLE_SEGMENTS=512 (the oracle calls run on a thread pool: ctypes drops the GIL)
+    # exact agreement with the CPU oracle on 1 024 sampled segments (all fields of all spots, in order); a longer
+    # soak: WSPR_CONFIG3_ORACLE_SEGMENTS=2048 (the oracle calls run on a thread pool: ctypes drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "128"))
+    nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "1024"))
     picks = list(range(5, nseg, nseg // nsample))
     Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:

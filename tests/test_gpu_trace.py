@@ -31,21 +31,22 @@ def test_trace_of_the_parity_batch_equals_oracle(w, opts):
     assert total >= 8 and undecoded >= 1          # candidates that never decode are compared too
 
 
-def test_trace_of_forty_random_scenes_equals_oracle(w):
+def test_trace_of_random_scenes_equals_oracle(w):
+    """120 random scenes (a longer soak: WSPR_TRACE_SCENES=300 python tests/trace_parity.py scenes)."""
     from test_gpu_parity import random_scenes
-    I, Q = random_scenes(40)
+    I, Q = random_scenes(120)
     total, undecoded = tp.check(I, Q, w, ol, None, "scenes")
-    assert total > 100 and undecoded > 30
+    assert total > 300 and undecoded > 90
 
 
 def test_trace_of_config3_segments_equals_oracle(w):
-    """64 segments of configs[2] (ten overlapping signals, -10..-28 dB): ~780 candidate visits over two passes, the
+    """256 segments of configs[2] (ten overlapping signals, -10..-28 dB): ~3 000 candidate visits over two passes, the
     subtractions in between, most of the ladder walks ending in Fano time-outs."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
     torch.cuda.set_device(0)
-    n = int(os.environ.get("WSPR_TRACE_CONFIG3", "64"))
+    n = int(os.environ.get("WSPR_TRACE_CONFIG3", "256"))
     I, Q, _ = bench.synth_batch_gpu(n, 4321, torch.device("cuda", 0), 10, -10.0, -28.0, 0.3)
     total, undecoded = tp.check(I.cpu().numpy(), Q.cpu().numpy(), w, ol, None, "config3")
     assert total >= 9 * n and undecoded >= n
