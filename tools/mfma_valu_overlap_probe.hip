@@ -42,6 +42,47 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, float
     out[tid] = s;
 }
 
+// wave specialisation: waves 0-3 of a 512-thread workgroup only multiply on the matrix pipe, waves 4-7 only add -- every
+// SIMD holds one wave of each kind, no instruction of one depends on the other
+__global__ __launch_bounds__(512) void probe_split(const float* __restrict__ in, float* __restrict__ out, int iters, int which) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = in[tid & 1023], b = in[(tid + 7) & 1023];
+    v32f acc, p0;
+    for (int r = 0; r < 32; ++r) { acc[r] = 0.0f; p0[r] = in[(tid + r) & 1023]; }
+    const v32f zero = {};
+    const bool mfma_wave = threadIdx.x < 256;
+    if (mfma_wave && (which & 2)) {
+        for (int it = 0; it < iters; ++it) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0);
+            a += p0[0];
+        }
+    } else if (!mfma_wave && (which & 1)) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 32; r += 2) {
+                v2f x = {acc[r], acc[r + 1]}, y = {p0[r], p0[r + 1]};
+                x = x + y;
+                acc[r] = x.x; acc[r + 1] = x.y;
+            }
+        }
+    }
+    float s = a;
+    for (int r = 0; r < 32; ++r) s += acc[r] + p0[r];
+    out[tid] = s;
+}
+
+float run_split(int which, int iters, const float* in, float* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe_split, dim3(256), dim3(512), 0, 0, in, out, iters, which);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(probe_split, dim3(256), dim3(512), 0, 0, in, out, iters, which);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
 template <int kMode> float run(int wgs, int iters, const float* in, float* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -68,5 +109,8 @@ int main() {
                "both / (adds + MFMA) = %.2f, both / max = %.2f\n", wps, t1, t1 * 1e6 / trips, t2, t2 * 1e6 / trips, t3, t3 * 1e6 / trips,
                t3 / (t1 + t2), t3 / (t1 > t2 ? t1 : t2));
     }
+    const float s1 = run_split(1, iters, in, out), s2 = run_split(2, iters, in, out), s3 = run_split(3, iters, in, out);
+    printf("wave-specialised (one adding wave and one multiplying wave per SIMD): adding waves alone %.3f ms, multiplying waves alone %.3f ms, "
+           "both kinds at once %.3f ms; both / max = %.2f\n", s1, s2, s3, s3 / (s1 > s2 ? s1 : s2));
     return 0;
 }
