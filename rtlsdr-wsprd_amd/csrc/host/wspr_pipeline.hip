@@ -369,6 +369,7 @@ size_t Context::release_buffers() {
             if (!g_ctx[dev][lane][i]) continue;
             Impl& c = *g_ctx[dev][lane][i]->d;
             HIP_OK(hipStreamSynchronize(c.stream));
+            if (c.fe_stream) HIP_OK(hipStreamSynchronize(c.fe_stream));
             for (DevBuf* b : {&c.iqI, &c.iqQ, &c.ps, &c.cand, &c.npk, &c.noise, &c.smspec, &c.seglist, &c.items, &c.syncbuf,
                               &c.symbuf, &c.rmsbuf, &c.jobs, &c.subscratch, &c.nvalid, &c.decscratch, &c.tabs, &c.pw, &c.pwfreq,
                               &c.lists, &c.scrsync, &c.psavg, &c.fz_sym, &c.fz_off, &c.fz_ret, &c.fz_cyc, &c.fz_met, &c.fz_max,
