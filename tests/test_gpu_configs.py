@@ -69,7 +69,8 @@ def test_config3_8192_segments_x_10_signals(env):
     # soak: WSPR_CONFIG3_ORACLE_SEGMENTS=2048 (the oracle calls run on a thread pool: ctypes drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
     nsample = int(os.environ.get("WSPR_CONFIG3_ORACLE_SEGMENTS", "1024"))
-    picks = list(range(5, nseg, nseg // nsample))
+    step = max(1, nseg // nsample)
+    picks = list(range(5 % step, nseg, step))          # WSPR_CONFIG3_ORACLE_SEGMENTS=8192: every segment
     Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
         refs = list(pool.map(lambda s: ol.decode(Ih[s], Qh[s], NS)[0], picks))
