@@ -250,7 +250,10 @@ void fano_wave_kernel(const unsigned char* __restrict__ symbols, const int* __re
 }  // namespace
 
 // resident grid: 13 single-wave workgroups per CU by LDS (11.5 KB each); a persistent loop takes the vectors
-constexpr int kWaveGrid = 256 * 13;
+#ifndef WSPR_K6W_PER_CU
+#define WSPR_K6W_PER_CU 13
+#endif
+constexpr int kWaveGrid = 256 * WSPR_K6W_PER_CU;
 
 size_t fano_wave_scratch_words(int n) {                     // the waves' stack slices + the work counter
     return (size_t)std::min(n, kWaveGrid) * 5 * 4096 + 16;
