@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# The HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share
+# a queue serialise.  With the GPU to itself this benchmark gains 1-3 % from sixteen (GPU_MAX_HW_QUEUES=16 python
+# bench.py: 221 -> 215 ms per configs[2] step in two calls, 220 -> 218 in a third), but more than sixteen queues on one
+# device IN TOTAL take turns (24 in one process: 290-357 ms; this process' sixteen plus the sixteen of the
+# per_rank_share_of_8 child: 289 ms for the child), so the default is left alone.
 import numpy as np
 import torch
 
