@@ -332,34 +332,84 @@ def reference_case_block(with_cpu):
     return blk
 
 
-def share_of_8_block(args, inflight):
-    """What ONE rank of an 8-rank job on this host gets: configs[2] again in a child process whose library sees 1/8 of
-    the usable CPUs (WSPR_HOST_THREADS), same batches in flight.  A SCALE value at N = 8 can be read against 8 x this
-    figure: below it the curve is limited by something other than the ranks' CPU shares."""
-    share = max(1, usable_cpus() // 8)
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env["WSPR_HOST_THREADS"] = str(share)
-    env["OMP_NUM_THREADS"] = str(share)
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", "3", "--steps", "8", "--warmup", "3", "--no-cpu-baseline",
-           "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case", "--no-ceilings",
-           "--inflight", str(inflight)]
+def child_bench(args, config, steps, warmup, inflight=None, cpu_share=None, spawn=False, timeout=600):
+    """One more bench.py run in a child process (slim: no baselines, no extra blocks) and its parsed JSON line:
+    with cpu_share the child is pinned to that many CPUs (--cpu-share), with spawn it runs as one rank under
+    torch.distributed.run with the RCCL process group (--spawn)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "WSPR_HOST_THREADS",
+                                                             "OMP_NUM_THREADS")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case",
+           "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-kernel-roofline"]
+    if inflight:
+        cmd += ["--inflight", str(inflight)]
+    if cpu_share:
+        cmd += ["--cpu-share", str(cpu_share)]
+    if spawn:
+        cmd += ["--spawn"]
     if args.segments:
         cmd += ["--segments", str(args.segments)]
     if args.slots:
         cmd += ["--slots", str(args.slots)]
-    import subprocess
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": "child bench failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
     d = json.loads(lines[-1])
-    return {"workload": d["config"]["workload"], "host_threads": d["host_threads"], "of_usable_cpus": usable_cpus(),
-            "batches_in_flight": d["config"]["batches_in_flight"], "value": d["value"], "unit": "segments/s",
-            "ms_per_step": d["ms_per_step"], "steps": d["steps"], "decoded_ok": d["decoded_ok"],
-            "false_decodes": d["false_decodes"], "host_pool_workers": d.get("host_pool_workers"),
-            "expected_8_gpu_aggregate": 8 * d["value"], "child_wall_s": time.perf_counter() - t0,
-            "note": "same GPU, same kernels; the host side (lane threads, bookkeeping, copies) runs on %d CPU(s)" % share}
+    d["child_wall_s"] = time.perf_counter() - t0
+    return d
+
+
+def slim(d):
+    """The figures of a child line that the blocks of the parent line quote."""
+    if "error" in d:
+        return d
+    return {"value": d["value"], "unit": "segments/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "batches_in_flight": d["config"]["batches_in_flight"], "slots_per_batch": d["config"]["slots_per_batch"],
+            "host_threads": d["host_threads"], "cpus_pinned_to": d.get("cpus_pinned_to"),
+            "host_pool_workers": d.get("host_pool_workers"), "decoded_ok": d["decoded_ok"],
+            "false_decodes": d["false_decodes"], "gathered_over": d["config"]["gathered_over"],
+            "gather_ms_per_step": d.get("gather_ms_per_step"), "child_wall_s": d["child_wall_s"]}
+
+
+def share_of_8_block(args, inflight):
+    """What ONE rank of an 8-rank job on this host gets: configs[2] again in a child process PINNED to 1/8 of the usable
+    CPUs (sched_setaffinity: lane threads, HIP runtime threads and the library's pools all live there), same batches in
+    flight.  A SCALE value at N = 8 can be read against 8 x this figure: below it the curve is limited by something
+    other than the ranks' CPU shares."""
+    share = max(1, usable_cpus() // 8)
+    d = child_bench(args, 3, 8, 3, inflight=inflight, cpu_share=share)
+    if "error" in d:
+        return d
+    out = slim(d)
+    out.update({"workload": d["config"]["workload"], "of_usable_cpus": usable_cpus(), "expected_8_gpu_aggregate": 8 * d["value"],
+                "note": "same GPU, same kernels; the whole process (lane threads, bookkeeping, copies, runtime) pinned to %d CPU(s)" % share})
+    return out
+
+
+def shard_block(args, full_host):
+    """configs[3] = 65 536 segments over 8 GPUs has never run (no 8-GPU box in reach of this session): what CAN be measured
+    on one GPU is its per-rank shard -- 8 192 single-signal segments -- through the code an 8-rank run takes:
+      full_host      the shard with the whole host's CPUs (measured in this process by the caller),
+      share_of_8     the same in a child pinned to usable_cpus // 8 CPUs: the host-CPU limit of a rank,
+      rccl_world_1   the same as ONE RANK under torch.distributed.run with the RCCL process group: options broadcast,
+                     per-step SpotGatherer (staging copy, H2D, gather, D2H on rank 0): gather_ms_per_step.
+    8 x min(...) is what the sharded run can reach on this host if nothing else limits."""
+    share = max(1, usable_cpus() // 8)
+    blk = {"workload": full_host["workload"], "full_host": full_host,
+           "share_of_8": slim(child_bench(args, 4, 20, 4, cpu_share=share)),
+           "rccl_world_1": slim(child_bench(args, 4, 20, 4, spawn=True)),
+           "rccl_world_1_share_of_8": slim(child_bench(args, 4, 20, 4, cpu_share=share, spawn=True))}
+    vals = [v["value"] for v in (blk["full_host"], blk["share_of_8"], blk["rccl_world_1"], blk["rccl_world_1_share_of_8"]) if "value" in v]
+    if len(vals) == 4:
+        blk["share_of_8_over_full_host"] = blk["share_of_8"]["value"] / blk["full_host"]["value"]
+        g = blk["rccl_world_1_share_of_8"]
+        if g.get("gather_ms_per_step") is not None:
+            blk["gather_fraction_of_a_step"] = g["gather_ms_per_step"] / g["ms_per_step"]
+        blk["expected_8_gpu_aggregate_configs3"] = 8 * min(vals)
+    return blk
 
 
 def launch_ranks(n):
@@ -392,15 +442,21 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--segments", type=int, default=None, help="segments per GPU (default: the config's)")
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs index: 3 = configs[2] (8192 seg x 10 signals, -10..-28 dB, deep search "
                          "on; the headline: largest single-GPU configuration), 2 = configs[1] (1024 seg x 1 signal, "
-                         "-20 dB), 5 = configs[4] (raw 2.4 Msps u8 IQ through the on-GPU decimator; --segments = segments "
+                         "-20 dB), 4 = ONE RANK'S SHARD of configs[3] (65 536 segments over 8 GPUs = 8 192 single-signal "
+                         "segments per GPU, SURVEY 8d 'config 4 ... as config 2'; with --gpus 8 this IS configs[3]), "
+                         "5 = configs[4] (raw 2.4 Msps u8 IQ through the on-GPU decimator; --segments = segments "
                          "per decoder call, default 1024, fed by front-end waves of --raw-segments)")
     ap.add_argument("--raw-segments", type=int, default=64,
                     help="--config 5: distinct raw segments resident in HBM (576 MB each) = one front-end wave")
     ap.add_argument("--k0-cus", type=int, default=None,
                     help="--config 5: CUs the front end may occupy (wspr_set_front_end_cus; 0 = all)")
+    ap.add_argument("--cpu-share", type=int, default=None,
+                    help="run as ONE rank of a job that gives each rank this many CPUs: the process is pinned to that many "
+                         "CPUs (sched_setaffinity) and the library sizes its host side for them (WSPR_HOST_THREADS); "
+                         "what the per-rank blocks of the N=1 line use")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block of the N=1 line")
@@ -409,6 +465,12 @@ def main():
     ap.add_argument("--no-share-block", action="store_true",
                     help="skip the per_rank_share_of_8 block (configs[2] again in a child process with 1/8 of the CPUs)")
     ap.add_argument("--no-reference-case", action="store_true", help="skip the configs[0] block (one wspr_decode() call)")
+    ap.add_argument("--no-shard-block", action="store_true",
+                    help="skip the configs3_shard block (the per-rank shard of configs[3]: full host, 1/8 of the CPUs, world-1 RCCL)")
+    ap.add_argument("--no-host-entry", action="store_true",
+                    help="skip the host_entry block (the reference's own calling convention: host buffers in, wsprd.h:106-111)")
+    ap.add_argument("--no-kernel-roofline", action="store_true",
+                    help="child runs: skip the kernel-level timing sets behind the roofline block (the line then carries no roofline)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 --pmc passes (about 40 s); read it from profiles/")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
@@ -418,6 +480,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight (default: 12 for --config 3, 12 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1; 6 for --config 5): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
+    ap.add_argument("--inflight-light", type=int, default=None,
+                    help="batches in flight for the single-signal workloads (--config 2 / 4) when --inflight is not given")
     ap.add_argument("--slots", type=int, default=None,
                     help="concurrent pipelines per batch inside the library (wspr_set_thread_slots; default: 1 with four or more "
                          "batches in flight -- they already overlap each other -- else the library's own 3)")
@@ -425,6 +489,14 @@ def main():
                     help="take the launcher path even for --gpus 1 (one rank under torch.distributed.run with the RCCL "
                          "process group, broadcast and gather): how the multi-GPU entry is exercised on a 1-GPU box")
     args = ap.parse_args()
+    if args.cpu_share:
+        # an honest emulation of a rank's CPU share: the lane threads, the HIP runtime's threads and torch's all
+        # live on these CPUs (WSPR_HOST_THREADS alone only sizes the library's pools)
+        cpus = sorted(os.sched_getaffinity(0))[:max(1, args.cpu_share)]
+        os.sched_setaffinity(0, cpus)
+        os.environ["WSPR_HOST_THREADS"] = str(len(cpus))
+        os.environ["OMP_NUM_THREADS"] = str(len(cpus))
+        torch.set_num_threads(len(cpus))
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         launch_ranks(args.gpus)                          # does not return: re-executes under torch.distributed.run
@@ -483,6 +555,8 @@ def main():
     # 3.19-3.24 with 1 x 12.  configs[4] does not care (197-201 ms with 3 x 6 or 1 x 6) and holds 147 GB of raw data
     # resident, so it stays at six.  With few CPUs per rank: two in flight, or one.
     def default_inflight(config):
+        if args.inflight_light and config in (2, 4):
+            return args.inflight_light
         return 12 if config == 3 else (6 if config == 5 else (12 if cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
     inflight = max(1, min(args.inflight if args.inflight else default_inflight(args.config), 16))
     from concurrent.futures import ThreadPoolExecutor
@@ -506,9 +580,12 @@ def main():
         """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds)."""
         fast_old = None
         inflight = lanes_primary if config == args.config else (min(args.inflight, 6) if args.inflight else default_inflight(config))
-        if config == 2:
+        if config in (2, 4):
             I, Q, expected = synth_batch_gpu(nseg, 1234 + seed, dev, 1, args.snr, args.snr, 1.0)
             workload = "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr)
+            if config == 4:
+                workload = ("configs[3], one rank's shard: %d of the 65 536 single-signal segments (8 GPUs x 8 192; SURVEY 8d: "
+                            "'config 4 ... as config 2'), SNR %g dB, generated with the rank's seed" % (nseg, args.snr))
             raw = None
         elif config == 3:
             I, Q, expected = synth_batch_gpu(nseg, 4321 + seed, dev, 10, -10.0, -28.0, 0.3)
@@ -560,6 +637,8 @@ def main():
                 decs[k].decode(I, Q)
             return k, w.last_timings()                   # timings of THIS step, read on the lane that ran it
 
+        gather_s = [0.0, 0]                                  # seconds spent in the fan-in, gathers
+
         def run_steps(n):
             """n steps, at most `inflight` of them running; spot records are gathered in step order."""
             pending, last, tim, lastk = [], None, None, 0
@@ -568,23 +647,32 @@ def main():
                 if len(pending) >= inflight:
                     done, tim = pending.pop(0).result()
                     if use_dist:
+                        t_g = time.perf_counter()
                         gatherers[done].stage()               # results copied out: the lane is free again
+                        gather_s[0] += time.perf_counter() - t_g
                 pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
                 if done is not None and use_dist:
+                    t_g = time.perf_counter()
                     last = gatherers[done].exchange()         # every rank's records land on rank 0 (RCCL)
+                    gather_s[0] += time.perf_counter() - t_g
+                    gather_s[1] += 1
             for fut in pending:
                 lastk, tim = fut.result()
                 if use_dist:
+                    t_g = time.perf_counter()
                     last = gatherers[lastk].gather()
+                    gather_s[0] += time.perf_counter() - t_g
+                    gather_s[1] += 1
             return last, tim, lastk
 
         # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
         # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
-        untimed = max(warmup, {2: 4, 3: 2, 5: 1}[config] * inflight)
+        untimed = max(warmup, {2: 4, 3: 2, 4: 2, 5: 1}[config] * inflight)
         run_steps(untimed)
 
         def timed(n):
             fence()
+            gather_s[0], gather_s[1] = 0.0, 0
             t0 = time.perf_counter()
             out = run_steps(n)
             fence()
@@ -616,9 +704,11 @@ def main():
                 "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed, "slots": slots_used, "inflight": inflight,
                 "value": world * nseg * n_timed / elapsed, "ms_per_step": elapsed / n_timed * 1e3,
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
-                "timings": timings}
+                "timings": timings,
+                # the fan-in of the timed steps as the driving thread saw it (staging copy + H2D + gather + D2H on rank 0)
+                "gather_ms_per_step": (1e3 * gather_s[0] / gather_s[1]) if gather_s[1] else None}
 
-    nseg = args.segments or {2: 1024, 3: 8192, 5: 1024}[args.config]
+    nseg = args.segments or {2: 1024, 3: 8192, 4: 8192, 5: 1024}[args.config]
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
 
     fanout = None
@@ -648,98 +738,100 @@ def main():
 
     if rank == 0:
         I, Q = m["I"], m["Q"]
-        # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
-        ms = (C.c_double * 8)()
-        L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 10, C.addressof(ms))
-        k1, k2, k3 = ms[0], ms[1], ms[2]
-        traffic, traffic_src = None, None
-        if world == 1 and not use_dist and not args.no_pmc and args.config in (2, 3):
-            # measured in this run (the verdict of round 2: a number read from profiles/ goes stale when a kernel changes)
-            pm = measure_k1_traffic(nseg, 10 if args.config == 3 else 1)
-            if pm and pm.get("hbm_bytes_per_segment"):
-                traffic = pm["hbm_bytes_per_segment"] * nseg
-                kk = pm["kernels"][pm["dominant_kernel"]]
-                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_k1.py "
-                               "%d %d; read %.3f GB + written %.3f GB per launch; FETCH_SIZE x %.3f, WRITE_SIZE x %.3f by the 1 GiB "
-                               "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
-                                         pm["calibration"]["true_bytes_per_counted_read_byte"],
-                                         pm["calibration"]["true_bytes_per_counted_written_byte"]))
-        for name in (() if traffic else ("r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
-            tf = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tf):
-                jd = json.load(open(tf))
-                per_seg = jd.get("hbm_bytes_per_segment") or (jd.get("hbm_bytes_per_launch", 0) / jd.get("segments", 1024))
-                if per_seg:
-                    traffic, traffic_src = per_seg * nseg, "profiles/" + name
-                    break
-        roof = {"bound": "hbm", "kernel": "fft_bank_avg_kernel<4> (K1 fused with the time average)" if nseg >= 256
-                else "fft_bank_kernel<4> (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k1,
-                "bytes_per_launch": K1_BYTES * nseg,
-                # what the kernel really moves (PMC): the fused form does not send the 106 bin rows that only the
-                # time average needed to HBM, so its traffic is BELOW the algorithmic figure of SURVEY 8(d)
-                "traffic_GBs": (traffic / (k1 * 1e-3) / 1e9) if traffic else None,
-                "traffic_frac_of_peak": (traffic / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
-                                   "wall_ms": ms[4],
-                                   "bytes_per_launch": STAGE_BYTES * nseg,
-                                   "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
-                                   "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-        # ---- the fp32-VALU-bound kernels: tiled lag scan (K4 mode 0), frequency scan + first rung, subtraction (K7)
-        vms = (C.c_double * 8)()
-        L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
-        if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 5, C.addressof(vms)) > 0 and vms[2] > 0:   # five timed passes after an untimed one
-            def valu(flop_each, n, t_ms):
-                tf = flop_each * n / (t_ms * 1e-3) / 1e12
-                return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
-                        "frac_of_no_fma_bound": tf / VALU_NOFMA_TF}
-            mtf = C.c_double(0.0)
-            L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
-            L.wspr_calib_valu(20, C.addressof(mtf))
-            roof["valu"] = {"peak_TFs": VALU_PEAK_TF, "no_fma_bound_TFs": VALU_NOFMA_TF,
-                            # register-only v_pk_mul_f32 + v_pk_add_f32 chains on every SIMD: the practical ceiling
-                            "measured_no_fma_TFs": mtf.value,
-                            "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
-                                    "half the FMA peak",
-                            "K4_lag_scan (demod_lagsys_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
-                            "K4_freq_scan_first_rung (freq_scalar_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
-                            "K7_subtract (sub_runs_wave_kernel + sub_fir_fused_kernel)": valu(K7_FLOP, vms[3], vms[1])}
-        # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
-        # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
-        if args.config != 5 and not args.no_ceilings:
-            n_copy = 1 << 28
-            src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
-            dst = torch.empty_like(src)
-            torch.cuda.synchronize()
-            L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
-            t0 = time.perf_counter()
-            L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
-            roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
-            # the tuned copy (16 bytes per lane, four loads in flight per lane, resident grid), by cache policy: HIP events
-            L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
-            cms = C.c_double(0.0)
-            tuned = {}
-            for variant, name in ((0, "nontemporal_loads_and_stores"), (1, "nontemporal_stores"), (2, "default_policy")):
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, variant, None)
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, variant,
-                                    C.addressof(cms))
-                tuned[name] = 8.0 * n_copy / (cms.value * 1e-3) / 1e9
-            roof["measured_copy16_GBs"] = max(tuned.values())            # the ceiling of mixed read + write traffic here
-            roof["measured_copy16_by_policy_GBs"] = tuned
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 3, None)
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 3, C.addressof(cms))
-            roof["measured_write_only_GBs"] = 4.0 * n_copy / (cms.value * 1e-3) / 1e9
-            # ... and write-only in the spectrogram's pattern (64-byte pieces of 311 rows per group of 16 time blocks)
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 4, None)
-            L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 4, C.addressof(cms))
-            roof["measured_write_only_spectrogram_pattern_GBs"] = (n_copy // (417 * 352)) * 311 * 22 * 64 / (cms.value * 1e-3) / 1e9
-            rd = (C.c_double * 1)()                                       # read-only: K0's access pattern over the same bytes
-            L.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
-            roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
-            del src, dst
+        roof = None
+        if not args.no_kernel_roofline:
+            # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
+            ms = (C.c_double * 8)()
+            L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 10, C.addressof(ms))
+            k1, k2, k3 = ms[0], ms[1], ms[2]
+            traffic, traffic_src = None, None
+            if world == 1 and not use_dist and not args.no_pmc and args.config in (2, 3, 4):
+                # measured in this run (the verdict of round 2: a number read from profiles/ goes stale when a kernel changes)
+                pm = measure_k1_traffic(nseg, 10 if args.config == 3 else 1)
+                if pm and pm.get("hbm_bytes_per_segment"):
+                    traffic = pm["hbm_bytes_per_segment"] * nseg
+                    kk = pm["kernels"][pm["dominant_kernel"]]
+                    traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_k1.py "
+                                   "%d %d; read %.3f GB + written %.3f GB per launch; FETCH_SIZE x %.3f, WRITE_SIZE x %.3f by the 1 GiB "
+                                   "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
+                                             pm["calibration"]["true_bytes_per_counted_read_byte"],
+                                             pm["calibration"]["true_bytes_per_counted_written_byte"]))
+            for name in (() if traffic else ("r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
+                tf = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tf):
+                    jd = json.load(open(tf))
+                    per_seg = jd.get("hbm_bytes_per_segment") or (jd.get("hbm_bytes_per_launch", 0) / jd.get("segments", 1024))
+                    if per_seg:
+                        traffic, traffic_src = per_seg * nseg, "profiles/" + name
+                        break
+            roof = {"bound": "hbm", "kernel": "fft_bank_avg_kernel<4> (K1 fused with the time average)" if nseg >= 256
+                    else "fft_bank_kernel<4> (K1)", "achieved": K1_BYTES * nseg / (k1 * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": K1_BYTES * nseg / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k1,
+                    "bytes_per_launch": K1_BYTES * nseg,
+                    # what the kernel really moves (PMC): the fused form does not send the 106 bin rows that only the
+                    # time average needed to HBM, so its traffic is BELOW the algorithmic figure of SURVEY 8(d)
+                    "traffic_GBs": (traffic / (k1 * 1e-3) / 1e9) if traffic else None,
+                    "traffic_frac_of_peak": (traffic / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "fft_sync_stage": {"kernels_ms": {"fft_bank": k1, "pick_peaks": k2, "coarse_sync": k3},
+                                       "wall_ms": ms[4],
+                                       "bytes_per_launch": STAGE_BYTES * nseg,
+                                       "achieved_GBs": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9,
+                                       "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            # ---- the fp32-VALU-bound kernels: tiled lag scan (K4 mode 0), frequency scan + first rung, subtraction (K7)
+            vms = (C.c_double * 8)()
+            L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+            if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 5, C.addressof(vms)) > 0 and vms[2] > 0:   # five timed passes after an untimed one
+                def valu(flop_each, n, t_ms):
+                    tf = flop_each * n / (t_ms * 1e-3) / 1e12
+                    return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
+                            "frac_of_no_fma_bound": tf / VALU_NOFMA_TF}
+                mtf = C.c_double(0.0)
+                L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
+                L.wspr_calib_valu(20, C.addressof(mtf))
+                roof["valu"] = {"peak_TFs": VALU_PEAK_TF, "no_fma_bound_TFs": VALU_NOFMA_TF,
+                                # register-only v_pk_mul_f32 + v_pk_add_f32 chains on every SIMD: the practical ceiling
+                                "measured_no_fma_TFs": mtf.value,
+                                "note": "separately rounded mul/add (no FMA, by parity): the packed-fp32 pipes issue at most "
+                                        "half the FMA peak",
+                                "K4_lag_scan (demod_lagsys_kernel + demod_metric_kernel)": valu(K4_FLOP, vms[2], vms[0]),
+                                "K4_freq_scan_first_rung (freq_scalar_kernel + ...)": valu(K41_FLOP, vms[2], vms[4]),
+                                "K7_subtract (sub_runs_wave_kernel + sub_fir_fused_kernel)": valu(K7_FLOP, vms[3], vms[1])}
+            # measured ceiling: the library's plain stream-copy kernel over 1 GiB (read + write, far beyond
+            # the 256 MiB Infinity Cache), same stream and launch path as the kernels above
+            if args.config != 5 and not args.no_ceilings:
+                n_copy = 1 << 28
+                src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
+                dst = torch.empty_like(src)
+                torch.cuda.synchronize()
+                L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
+                t0 = time.perf_counter()
+                L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
+                roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
+                # the tuned copy (16 bytes per lane, four loads in flight per lane, resident grid), by cache policy: HIP events
+                L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+                cms = C.c_double(0.0)
+                tuned = {}
+                for variant, name in ((0, "nontemporal_loads_and_stores"), (1, "nontemporal_stores"), (2, "default_policy")):
+                    L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, variant, None)
+                    L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, variant,
+                                        C.addressof(cms))
+                    tuned[name] = 8.0 * n_copy / (cms.value * 1e-3) / 1e9
+                roof["measured_copy16_GBs"] = max(tuned.values())            # the ceiling of mixed read + write traffic here
+                roof["measured_copy16_by_policy_GBs"] = tuned
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 3, None)
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 3, C.addressof(cms))
+                roof["measured_write_only_GBs"] = 4.0 * n_copy / (cms.value * 1e-3) / 1e9
+                # ... and write-only in the spectrogram's pattern (64-byte pieces of 311 rows per group of 16 time blocks)
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 4, None)
+                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 4, C.addressof(cms))
+                roof["measured_write_only_spectrogram_pattern_GBs"] = (n_copy // (417 * 352)) * 311 * 22 * 64 / (cms.value * 1e-3) / 1e9
+                rd = (C.c_double * 1)()                                       # read-only: K0's access pattern over the same bytes
+                L.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
+                roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
+                del src, dst
         cpu = None
-        if args.config == 5:
+        if args.config == 5 and roof is not None:
             roof["front_end_K0"] = k0_report(L, m, world == 1 and not args.no_cpu_baseline)
             cpu = roof["front_end_K0"].pop("cpu_baseline", None)
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
@@ -774,6 +866,22 @@ def main():
                         "front_end_K0": k0_report(L, m3, not args.no_cpu_baseline)}
             del m3
             torch.cuda.empty_cache()
+        shard = None
+        if world == 1 and args.config == 3 and not args.no_shard_block and not use_dist:
+            # configs[3]'s per-rank shard (8 192 single-signal segments): in this process with the whole host, then in
+            # children with a rank's CPU share and as a world-1 RCCL rank
+            I = Q = None
+            m["I"] = m["Q"] = None
+            torch.cuda.empty_cache()
+            L.wspr_release_buffers()
+            m4 = measure(4, 8192, 30, 4, rank)
+            full = {"value": m4["value"], "unit": "segments/s", "ms_per_step": m4["ms_per_step"], "steps": m4["steps"],
+                    "batches_in_flight": m4["inflight"], "slots_per_batch": m4["slots"], "workload": m4["workload"],
+                    "decoded_ok": m4["decoded_ok"], "false_decodes": m4["false_decodes"], "stage_ms_last_step": m4["timings"]}
+            del m4
+            torch.cuda.empty_cache()
+            L.wspr_release_buffers()
+            shard = shard_block(args, full)
         out = {
             "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
             "unit": "segments/s", "n_gpus": world, "distinct_devices": distinct_devices,
@@ -792,10 +900,12 @@ def main():
             "stage_ms_last_step": dict(m["timings"], note="times: maximum over the slots of the lane that ran the last "
                                                          "step; counts: sum over its slots"),
             "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
+            "cpus_pinned_to": len(os.sched_getaffinity(0)) if args.cpu_share else None,
+            "gather_ms_per_step": m.get("gather_ms_per_step"),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
             "host_pool_workers": int(L.wspr_host_pool_workers()),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,
-            "fanout_check": fanout,
+            "configs3_shard": shard, "fanout_check": fanout,
         }
         if world == 1 and not use_dist and args.config == 3:
             if not args.no_reference_case:

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <mutex>
 #include <stdexcept>
@@ -66,6 +67,7 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
                  int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
                  wspr_trace* trace = nullptr) {
     const int nslots = (nseg >= 128) ? Context::slot_cap() : 1;
+    Context::note_slots_used(nslots);
     Context& c0 = Context::get();
     if (nslots == 1) {
         load(c0, 0, nseg);
@@ -231,13 +233,27 @@ void wspr_shard_range(int nseg, int shard, int nshards, int* lo, int* hi) {
 // share they were sized for.)
 namespace {
 struct NodeShareGuard {
-    static std::atomic<int>& active() { static std::atomic<int> n{0}; return n; }
-    explicit NodeShareGuard(int ndevices) {
-        active().fetch_add(1);
-        int prev = wspr::node_share().load();
-        while (prev < ndevices && !wspr::node_share().compare_exchange_weak(prev, ndevices)) {}
+    // live shares and the published maximum change together under one mutex: a guard that ends while another call
+    // begins can no longer publish a share of 1 over the newcomer's (advisor, round 4)
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<int>& live() { static std::vector<int> v; return v; }
+    static void publish() {
+        int share = 1;
+        for (int n : live()) share = std::max(share, n);
+        wspr::node_share().store(share);
     }
-    ~NodeShareGuard() { if (active().fetch_sub(1) == 1) wspr::node_share().store(1); }
+    int mine;
+    explicit NodeShareGuard(int ndevices) : mine(ndevices) {
+        std::lock_guard<std::mutex> g(mu());
+        live().push_back(mine);
+        publish();
+    }
+    ~NodeShareGuard() {
+        std::lock_guard<std::mutex> g(mu());
+        auto& v = live();
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == mine) { v.erase(v.begin() + (long)i); break; }
+        publish();
+    }
 };
 }  // namespace
 
@@ -460,13 +476,18 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
 int wspr_host_pool_workers(void) { return wspr::pool_workers_alive().load(); }
 
 int wspr_last_timings(double* ms, int capacity) {
-    // times: the slowest slot (slots run concurrently); counts (index >= 7): summed over the slots
+    // times: the slowest slot (slots run concurrently); counts (index >= 7): summed over the slots -- of the slots
+    // the calling thread's LAST batch call ran on (a capped or small call uses fewer than Context::slots(); contexts
+    // are never created here)
     try {
         double acc[16] = {0};
-        int n = 0;
-        for (int g = 0; g < Context::slots(); ++g) {
+        int n = 16;
+        const int used = std::max(1, Context::last_slots_used());
+        for (int g = 0; g < used; ++g) {
+            Context* c = Context::slot_if_exists(g);
+            if (!c) continue;
             double t[16] = {0};
-            n = Context::slot(g).last_timings(t, 16);
+            n = c->last_timings(t, 16);
             for (int i = 0; i < n; ++i) acc[i] = (i < 7) ? (t[i] > acc[i] ? t[i] : acc[i]) : acc[i] + t[i];
         }
         n = n < capacity ? n : capacity;

@@ -62,6 +62,9 @@ public:
     static void cap_slots(int n);   // calling thread: use at most n slots per batch (a shard's share of the host)
     static size_t release_buffers();   // current device, every lane and slot: bytes of device memory returned
     static int slot_cap();          // min(slots(), the thread's cap, the CPUs of its share)
+    static Context* slot_if_exists(int i);   // slot i of the calling thread's (device, lane) if it was ever created
+    static void note_slots_used(int n);      // slots the calling thread's current batch call runs on ...
+    static int last_slots_used();            // ... as wspr_last_timings() reads it back
     int device();
     ~Context();
 

@@ -357,6 +357,16 @@ Context& Context::slot(int i) {
 
 Context& Context::get() { return slot(0); }
 
+Context* Context::slot_if_exists(int i) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || i < 0 || i >= 8) return nullptr;
+    std::lock_guard<std::mutex> g(g_ctx_mutex);
+    return g_ctx[dev][t_lane][i].get();
+}
+static thread_local int t_slots_used = 1;
+void Context::note_slots_used(int n) { t_slots_used = std::max(1, n); }
+int Context::last_slots_used() { return t_slots_used; }
+
 // Work buffers (device and pinned) of every context of the current device go back to the driver; the constant
 // tables, streams and host pools stay, the next call allocates what it needs.  No call may be in flight.
 size_t Context::release_buffers() {

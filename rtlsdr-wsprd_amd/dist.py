@@ -110,24 +110,31 @@ def in_rank_order(fn):
     nonce = [uuid.uuid4().hex if rank == 0 else None]
     dist.broadcast_object_list(nonce, src=0)
     probe = ".wspr_rank_order_%s" % nonce[0]
-    if rank == 0:
-        with open(probe, "w") as f:
-            f.write(nonce[0])
-            f.flush()
-            os.fsync(f.fileno())
-    dist.barrier()
+    # Rank 0 may be unable to write (read-only or vanished working directory): it must still reach the barrier and the
+    # all_gather below, or every other rank waits there for the collective time-out; the probe is removed on every path.
     try:
-        with open(probe) as f:
-            seen = f.read() == nonce[0]
-    except OSError:
-        seen = False
-    sees = [None] * world
-    dist.all_gather_object(sees, (seen, os.uname().nodename, os.getcwd()))
-    if rank == 0:
+        if rank == 0:
+            try:
+                with open(probe, "w") as f:
+                    f.write(nonce[0])
+                    f.flush()
+                    os.fsync(f.fileno())
+            except OSError:
+                pass                            # every rank, this one included, then reports seen = False below
+        dist.barrier()
         try:
-            os.unlink(probe)
+            with open(probe) as f:
+                seen = f.read() == nonce[0]
         except OSError:
-            pass
+            seen = False
+        sees = [None] * world
+        dist.all_gather_object(sees, (seen, os.uname().nodename, os.getcwd()))
+    finally:
+        if rank == 0:
+            try:
+                os.unlink(probe)
+            except OSError:
+                pass
     if not all(x[0] for x in sees):
         raise RuntimeError("in_rank_order: the ranks do not share one working directory (hashtable.txt): %r" % (sees,))
     out, err = None, None

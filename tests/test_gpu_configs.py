@@ -97,6 +97,58 @@ def test_config3_8192_segments_x_10_signals(env):
         L.wspr_set_fano_device_mode(old_mode)
 
 
+# ------------------------------------------------------------------ configs[3], one rank's shard
+def test_config4_shard_of_configs3_8192_single_signal_segments(env):
+    """configs[3] = 65 536 segments over 8 GPUs: no 8-GPU box is in reach of the suite, but its per-rank workload -- the
+    dist.shard_range() block of 8 192 SINGLE-SIGNAL segments ('config 4 ... as config 2'; the independence that
+    makes it shardable: wsprd.c:478-479) -- had never run anywhere (verdict of round 4: the largest single-signal batch
+    under test was 1 024).  Rank 3's block, generated with that rank's seed as bench.py --config 4 / --gpus 8 does:
+    decode rate, no false decode, 512 sampled segments equal the oracle field for field, the two halves and a
+    permutation of the block give the same spots (what makes the shard boundaries irrelevant)."""
+    torch, bench, w, dev = env
+    from concurrent.futures import ThreadPoolExecutor
+    from rtlsdr_wsprd_amd import dist as wd
+    world, rank = 8, 3
+    lo, hi = wd.shard_range(65536, rank, world)
+    nseg = hi - lo
+    assert nseg == 8192
+    I, Q, expected = bench.synth_batch_gpu(nseg, 1234 + rank, dev, 1, -20.0, -20.0, 1.0)
+    dec = w.BatchDecoder(nseg, 16)
+    dec.decode(I, Q)
+    full = [[_tup(x) for x in dec.spots(s)] for s in range(nseg)]
+    msgs = [[t[0].decode() for t in seg] for seg in full]
+    n_ok = sum(expected[s][0] in msgs[s] for s in range(nseg))
+    n_false = sum(m not in expected[s] for s in range(nseg) for m in msgs[s])
+    print("configs[3] shard of rank %d: %d/%d decoded, %d false" % (rank, n_ok, nseg, n_false))
+    assert n_ok >= 0.95 * nseg and n_false == 0
+    # oracle-exact on 512 sampled segments (every 16th)
+    picks = list(range(7, nseg, 16))
+    Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        refs = list(pool.map(lambda s: ol.decode(Ih[s], Qh[s], NS)[0], picks))
+    assert len(picks) == 512
+    for s, ref in zip(picks, refs):
+        assert _same_as_oracle(dec.spots(s), ref), s
+    # the block's halves on their own (a 16-rank split of the same job) and a permutation of its rows
+    for a, b in ((0, nseg // 2), (nseg // 2, nseg)):
+        h = w.BatchDecoder(b - a, 16)
+        h.decode(I[a:b].contiguous(), Q[a:b].contiguous())
+        assert [[_tup(x) for x in h.spots(s)] for s in range(b - a)] == full[a:b]
+    perm = torch.randperm(nseg, generator=torch.Generator().manual_seed(65536)).to(dev)
+    p = w.BatchDecoder(nseg, 16)
+    p.decode(I[perm].contiguous(), Q[perm].contiguous())
+    pl = perm.cpu().numpy()
+    assert all([_tup(x) for x in p.spots(i)] == full[pl[i]] for i in range(nseg))
+    # the same block through the device-Fano mode a rank with a 1/8 CPU share runs by default
+    L = w.lib()
+    old_mode = L.wspr_set_fano_device_mode(1)
+    try:
+        dec.decode(I, Q)
+        assert [[_tup(x) for x in dec.spots(s)] for s in range(nseg)] == full
+    finally:
+        L.wspr_set_fano_device_mode(old_mode)
+
+
 # ------------------------------------------------------------------ configs[4]
 def test_config5_full_size_raw_segments_through_k0_and_decode(env):
     """Three complete 2-minute raw segments (576 000 000 bytes each): the config's signal level, a strong
@@ -137,6 +189,52 @@ def test_config5_full_size_raw_segments_through_k0_and_decode(env):
     # the CIC passes an in-band tone with a gain of 8.4e7 per LSB: 30 LSB would be 2.5e9 > 2^31, so the
     # second segment's comb outputs wrapped (its peak stays far below the linear value)
     assert peaks[1] < 0.9 * 30.0 * 8.3e7 and 30.0 * 8.3e7 > 2.0 ** 31
+
+
+def test_config5_64_distinct_raw_segments_in_waves(env):
+    """configs[4] beyond three segments (verdict of round 4): 64 DISTINCT full-size raw segments (36.9 GB resident), through
+    the front end in four waves of 16 into the rows of an IQ ring -- the shape bench.py --config 5 runs -- and one decoder
+    call over the 64 rows.  Every row's decimated IQ bit-exact vs the oracle front end (parity UNPINNED for this function:
+    oracle/orc_frontend.c has no reference-held fixture), every row's spots equal the oracle decoder's field for field."""
+    torch, bench, w, dev = env
+    from concurrent.futures import ThreadPoolExecutor
+    RAW = bench.RAW_BYTES
+    nraw, wave = 64, 16
+    raw, expected = bench.synth_raw_gpu(nraw, 4242, dev, -20.0)
+    L = w.lib()
+    stride = int(L.wspr_iq_stride())
+    dI = torch.zeros(nraw, stride, device=dev)
+    dQ = torch.zeros(nraw, stride, device=dev)
+    w.sync_torch()
+    row = stride * 4
+    for wv in range(nraw // wave):
+        assert L.wspr_decimate_u8_batch_device(raw.data_ptr() + wv * wave * RAW, RAW, wave, dI.data_ptr() + wv * wave * row,
+                                               dQ.data_ptr() + wv * wave * row, 1) == 0
+    dec = w.BatchDecoder(nraw, 32)
+    dec.decode_ptr(dI.data_ptr(), dQ.data_ptr(), NS, stride)
+    gi, gq = dI.cpu().numpy(), dQ.cpu().numpy()
+    O = ol.lib()
+
+    def one(s):
+        host = raw[s].cpu().numpy()
+        st = O.orc_decim_new()
+        oi = np.zeros(NS, np.float32); oq = np.zeros(NS, np.float32)
+        fill = O.orc_decim_feed(C.c_void_p(st), ol.ptr(host), RAW, ol.ptr(oi), ol.ptr(oq), 0, NS)
+        O.orc_decim_free(C.c_void_p(st))
+        O.orc_normalise(ol.ptr(oi), ol.ptr(oq), C.c_int(fill), C.c_int(NS))
+        ref, _, _ = ol.decode(oi, oq, NS)
+        return fill, oi, oq, ref
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:        # 576 MB per task in flight
+        outs = list(pool.map(one, range(nraw)))
+    n_dec = 0
+    for s, (fill, oi, oq, ref) in enumerate(outs):
+        assert fill == 44992
+        assert np.array_equal(gi[s, :NS], oi) and np.array_equal(gq[s, :NS], oq), s
+        assert _same_as_oracle(dec.spots(s), ref), s
+        n_dec += [x.message.decode() for x in dec.spots(s)] == expected[s]
+    print("configs[4]: %d distinct raw segments in %d front-end waves, %d/%d decode their message, all equal to the oracle"
+          % (nraw, nraw // wave, n_dec, nraw))
+    assert n_dec >= 0.9 * nraw
 
 
 # ------------------------------------------------------------------ reference-held golden lines

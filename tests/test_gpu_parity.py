@@ -696,20 +696,34 @@ def _oopt(use):
 # ------------------------------------------------------------------ K6 device Fano
 def test_wave_fano_equals_host_fano(w):
     """K6w (fano_wave.h): one wavefront per vector, 64 tree visits per step.  Return code, cycle count
-    and decoded bytes equal the host routine's (= the reference's fano.c) for decodable vectors, early
-    time-outs and full 810 000-cycle time-outs; metric/maxnp for decoded frames."""
+    and decoded bytes equal those of the REAL reference fano() (fano.c:87-238, compiled where it lies into
+    oracle/_ref/libwsprd_ref.so; the oracle's restatement where that file did not travel) with the branch metrics the
+    oracle derives as wsprd.c:467-473 does -- for decodable vectors, early time-outs and full 810 000-cycle time-outs;
+    metric/maxnp for decoded frames.  The product's own host routine must say the same (round 4 compared only those two:
+    HIP against product)."""
     import time
     L = w.lib()
+    O = ol.lib()
+    R = ol.ref_lib()
     rng = np.random.default_rng(18)
-    mt = (C.c_int * 256 * 2)(); L.wspr_fano_metric_table(mt)
+    mt_prod = (C.c_int * 256 * 2)(); L.wspr_fano_metric_table(mt_prod)
+    mt = (C.c_int * 256 * 2)(); O.orc_build_mettab(mt)
+    assert list(np.frombuffer(mt, np.int32)) == list(np.frombuffer(mt_prod, np.int32))
+    if R is not None:
+        checker, deint, enc_fn, inter = R.fano, R.deinterleave, R.encode, R.interleave     # the reference's own objects
+        print("wave fano: checked against oracle/_ref/libwsprd_ref.so (the reference's fano.c)")
+    else:
+        O.orc_fano.restype = C.c_int
+        checker, deint, enc_fn, inter = O.orc_fano, O.orc_deinterleave, O.orc_conv_encode, O.orc_interleave
+        print("wave fano: oracle/_ref absent, checked against oracle/liboracle.so")
     enc = (C.c_ubyte * 176)()
     vecs = []
     for t in range(360):
         data = [int(x) for x in rng.integers(0, 256, 7)] + [0, 0, 0, 0]
         data[6] &= 0xC0
-        L.encode(enc, (C.c_ubyte * 11)(*data), C.c_uint(11))
+        enc_fn(enc, (C.c_ubyte * 11)(*data), C.c_uint(11))
         bits = (C.c_ubyte * 162)(*list(enc)[:162])
-        L.interleave(bits)                                   # transmission order, as the demodulator emits
+        inter(bits)                                          # transmission order, as the demodulator emits
         sigma = [5, 25, 40, 50, 55, 60, 65, 75, 100, 150, 400, 1000][t % 12]
         vecs.append(np.clip(np.where(np.frombuffer(bits, np.uint8) > 0, 178, 78) + rng.normal(0, sigma, 162), 0, 255).astype(np.uint8))
     vecs += [np.full(162, 128, np.uint8), np.zeros(162, np.uint8), np.full(162, 255, np.uint8),
@@ -727,12 +741,18 @@ def test_wave_fano_equals_host_fano(w):
         nto = 0
         for i in range(n):
             s = (C.c_ubyte * 162)(*sym[i].tolist())
-            L.deinterleave(s)
+            deint(s)
             dec = (C.c_ubyte * 11)(); a = C.c_uint(); b = C.c_uint(); c = C.c_uint()
-            r = L.fano(C.byref(a), C.byref(b), C.byref(c), dec, s, C.c_uint(81), mt, C.c_int(60), C.c_uint(maxcycles))
+            r = checker(C.byref(a), C.byref(b), C.byref(c), dec, s, C.c_uint(81), mt, C.c_int(60), C.c_uint(maxcycles))
             assert (ret[i], cyc[i]) == (r, b.value), (i, maxcycles, ret[i], cyc[i], r, b.value)
             if r == 0:
                 assert (met[i], mnp[i]) == (a.value, c.value) and list(dat[i]) == list(dec)[:10], (i, maxcycles)
+            # ... and the product's host routine (wspr_message.cpp) agrees with the same checker
+            s2 = (C.c_ubyte * 162)(*sym[i].tolist())
+            L.deinterleave(s2)
+            dec2 = (C.c_ubyte * 11)(); a2 = C.c_uint(); b2 = C.c_uint(); c2 = C.c_uint()
+            r2 = L.fano(C.byref(a2), C.byref(b2), C.byref(c2), dec2, s2, C.c_uint(81), mt_prod, C.c_int(60), C.c_uint(maxcycles))
+            assert (r2, b2.value) == (r, b.value) and (r != 0 or (a2.value, c2.value, list(dec2)) == (a.value, c.value, list(dec))), (i, maxcycles)
             nto += r != 0
         print("wave fano: maxcycles %d, %d vectors, %d time-outs, %.1f ms, steps max %d mean %.0f" % (
             maxcycles, n, nto, dt * 1e3, steps.max(), steps.mean()))
