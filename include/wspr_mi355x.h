@@ -84,12 +84,51 @@ int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options op
  * go to decodes[s*max_results ...], n_results[s]: a segment's unique spots are ranked by SNR first and
  * the strongest max_results are returned (the reference allows 100, its caller holds 50).  Inputs are not
  * modified unless writeback != 0.  With options.usehashtable the hash memory orders the segments
- * (wsprd.c:481-494, 842-852), so the batch is decoded one segment at a time in index order, each exactly
- * like a reference call (hashtable.txt read before, written after): same spots as nseg calls of
- * wspr_decode(), without the batch parallelism. */
+ * (wsprd.c:481-494, 842-852): the result -- spots and hashtable.txt -- is that of nseg reference calls in index
+ * order, obtained in parallel (see wspr_decode_batch_hashed() below; rounds 2-4 decoded such a batch one segment at a
+ * time).  Calls with the option take turns, as each reads the file the previous one wrote. */
 int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results *decodes,
                       int max_results, int *n_results, int writeback);
+
+/* usehashtable on a batch, the general form.  The reference reads hashtable.txt before and writes it after
+ * every decode (wsprd.c:481-494, 842-852), so what a type-3 "<call>" message resolves to (wsprd_utils.c:296-300)
+ * depends on the ORDER of the segments.  wspr_decode_batch*() with options.usehashtable decodes the batch in parallel all
+ * the same: each segment logs its hash stores and look-ups, the logs are checked in index order, and only the segments
+ * whose look-ups would have seen something else are decoded again, to the fixed point -- same spots and same
+ * hashtable.txt as nseg reference calls in index order.  This entry adds what a job sharded over several processes /
+ * GPUs needs: the call's segments are global indices seg_index0 .. seg_index0 + nseg - 1, `prior` holds the stores of
+ * the other shards (any order; those of earlier segments take part), and the call's own stores come back in
+ * stores_out[0 .. *n_stores) (segment order; -3 if cap is too small).  *n_redecoded: segments decoded more than once.
+ * Protocol for R shards (rtlsdr-wsprd_amd/dist.py decode_hashed_sharded): every shard calls with no prior and
+ * WSPR_HASH_KEEP_FILE; the stores are exchanged; a shard whose predecessors' stores changed calls again with
+ * WSPR_HASH_REVISIT (same buffers and result arrays: only the affected segments are decoded again); when no store list
+ * changes any more, ONE process calls wspr_hash_commit() with all stores in segment order. */
+typedef struct wspr_hash_op {
+    int32_t seg;                /* global segment index */
+    int32_t slot;               /* 0 .. HASHTAB_SIZE - 1 */
+    int32_t kind;               /* 1 = type-1 store (call + locator), 2 = type-2 store (call only) */
+    char    call[13];
+    char    grid[5];
+    char    pad[2];
+} wspr_hash_op;
+#define WSPR_HASH_KEEP_FILE 1   /* do not write hashtable.txt (a shard of a larger job) */
+#define WSPR_HASH_REVISIT   2   /* the calling thread's previous hashed call once more, under a new `prior` */
+int wspr_decode_batch_hashed(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
+                             struct decoder_options options, struct decoder_results *decodes, int max_results,
+                             int *n_results, int writeback, int seg_index0, const wspr_hash_op *prior, int n_prior,
+                             int flags, wspr_hash_op *stores_out, int cap, int *n_stores, int *n_redecoded);
+/* hashtable.txt := hashtable.txt + stores, applied in the order given (the job's stores in segment order). */
+int wspr_hash_commit(const wspr_hash_op *stores, int n);
+
+/* Host buffers at speed.  wspr_decode() / wspr_decode_batch() take the caller's HOST memory as the reference does
+ * (wsprd.h:106-111; call sites rtlsdr_wsprd.c:316, :689).  Pageable memory is gathered through pinned chunks of the
+ * library (host memcpy + DMA, chunk k+1 gathered under the DMA of chunk k); PINNED memory goes to the device as a plain
+ * DMA with no host work.  The reference's callers allocate their I/Q buffers once (rtlsdr_wsprd.c:78-90, 331-336):
+ * pin them once with this (hipHostRegister; no HIP headers needed on the caller's side) and unpin before free().
+ * Returns 0 on success (also when the range is pinned already), -1 otherwise. */
+int wspr_pin_host_buffer(void *p, size_t bytes);
+int wspr_unpin_host_buffer(void *p);
 
 /* Same, with the IQ already resident in HBM (device pointers, same layout).
  * The input is copied to a working buffer and left untouched.  This is the
@@ -278,7 +317,10 @@ int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int sa
  * [2] device Fano tail (K6), [3] fine sync + demod, [4] subtract, [5] host Fano, [6] total wall time,
  * then counts: [7] Fano calls, [8] Fano time-outs, [9] Fano cycles, [10] candidates refined, [11] GPU
  * waves, [12] Fano attempts left to the device tail, [13] segments decoded a second time, [14] refined
- * candidates whose result was consumed (the others: speculation cut by a subtraction), [15] subtractions.
+ * candidates whose result was consumed (the others: speculation cut by a subtraction), [15] subtractions;
+ * then the CPU time (not wall time) the calling thread spent in the call, milliseconds: [16] all of it, by phase [17] pass
+ * start (candidate lists, re-ranking), [18] wave building, [19] fine search + first rung (launches, lists, gates),
+ * [20] ladder, [21] bookkeeping (unpack, re-encode, de-dup), [22] subtraction launches, [23] result hand-over.
  * Returns the number of values written (<= capacity). */
 int wspr_last_timings(double *ms, int capacity);
 /* Worker threads of the library's host pools alive in this process (the threads that call into the library are

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <algorithm>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -62,44 +63,80 @@ struct TempDev {
 namespace {
 // Splits a batch over the pipelines (slots).  Segments are independent, so every slot decodes a
 // contiguous share on its own stream while the others are in their host phases.
+// hb (usehashtable on a batch): the shared, ordered hash memory; after the first round the segments whose look-ups no
+// longer hold are decoded again, round by round, until none is left (see HashBatch in wspr_pipeline.h).
 template <class Load, class Reload>
 int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
                  int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
-                 wspr_trace* trace = nullptr) {
+                 wspr_trace* trace = nullptr, wspr::HashBatch* hb = nullptr, const std::vector<int>* revisit = nullptr) {
     const int nslots = (nseg >= 128) ? Context::slot_cap() : 1;
     Context::note_slots_used(nslots);
     Context& c0 = Context::get();
-    if (nslots == 1) {
-        load(c0, 0, nseg);
-        const int rc = c0.decode_resident(nseg, samples, options, decodes, max_results, n_results,
-                                          [&](const std::vector<int>& segs) { reload(c0, 0, segs); }, trace);
-        if (writeback) c0.store_host(idat, qdat, nseg, samples, seg_stride);
-        return rc;
-    }
     const int dev = c0.device(), lane = Context::lane();
-    std::vector<std::thread> th;
-    std::vector<int> rcs(nslots, 0);
-    std::vector<std::string> errs(nslots);
-    for (int g = 0; g < nslots; ++g) {
-        const int lo = (int)((long)nseg * g / nslots), hi = (int)((long)nseg * (g + 1) / nslots);
-        th.emplace_back([&, g, lo, hi] {
-            try {
-                if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-                Context::bind_lane(lane);
-                Context& c = Context::slot(g);
-                load(c, lo, hi - lo);
-                rcs[g] = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results,
-                                           n_results + lo, [&c, &reload, lo](const std::vector<int>& segs) { reload(c, lo, segs); },
-                                           trace ? trace + lo : nullptr);
-                if (writeback) c.store_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples, seg_stride);
-            } catch (const std::exception& e) { rcs[g] = -1; errs[g] = e.what(); }
+    struct Share { int lo, hi; };
+    std::vector<Share> share(nslots);
+    for (int g = 0; g < nslots; ++g) share[g] = {(int)((long)nseg * g / nslots), (int)((long)nseg * (g + 1) / nslots)};
+    // runs fn(g, context of slot g) for every slot, slot 0 on the calling thread when it is the only one
+    auto on_slots = [&](const std::function<void(int, Context&)>& fn) {
+        if (nslots == 1) { fn(0, c0); return; }
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(nslots);
+        std::vector<char> bad(nslots, 0);
+        for (int g = 0; g < nslots; ++g)
+            th.emplace_back([&, g] {
+                try {
+                    if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+                    Context::bind_lane(lane);
+                    fn(g, Context::slot(g));
+                } catch (const std::exception& e) { bad[g] = 1; errs[g] = e.what(); }
+            });
+        for (auto& t : th) t.join();
+        for (int g = 0; g < nslots; ++g)
+            if (bad[g]) throw std::runtime_error(errs[g].empty() ? "slot failed" : errs[g]);
+    };
+    auto again = [&](const std::vector<int>& todo) {         // global (call-relative) indices, ascending
+        on_slots([&](int g, Context& c) {
+            const int lo = share[g].lo, hi = share[g].hi;
+            std::vector<int> mine;
+            for (int t : todo) if (t >= lo && t < hi) mine.push_back(t - lo);
+            if (mine.empty()) return;
+            reload(c, lo, mine);
+            c.decode_again(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results, n_results + lo, mine, hb, lo);
         });
+    };
+    if (!revisit) {
+        on_slots([&](int g, Context& c) {
+            const int lo = share[g].lo, hi = share[g].hi;
+            load(c, lo, hi - lo);
+            const int rc = c.decode_resident(hi - lo, samples, options, decodes + (size_t)lo * max_results, max_results, n_results + lo,
+                                             [&c, &reload, lo](const std::vector<int>& segs) { reload(c, lo, segs); },
+                                             trace ? trace + lo : nullptr, hb, lo);
+            if (rc < 0) throw std::runtime_error("decode failed");
+        });
+    } else if (!revisit->empty()) {
+        // the batch of the previous call once more (its rows are still in the slots' working buffers, decoded): only
+        // the listed segments are restored and decoded again
+        ++hb->rounds; hb->redecoded += (int)revisit->size();
+        again(*revisit);
     }
-    for (auto& t : th) t.join();
-    for (int g = 0; g < nslots; ++g)
-        if (rcs[g] < 0) throw std::runtime_error(errs[g].empty() ? "slot failed" : errs[g]);
+    if (hb)
+        for (;;) {
+            hb->rebuild();
+            const std::vector<int> todo = hb->invalid();
+            if (todo.empty()) break;
+            ++hb->rounds; hb->redecoded += (int)todo.size();
+            again(todo);
+        }
+    if (writeback)
+        on_slots([&](int g, Context& c) {
+            const int lo = share[g].lo, hi = share[g].hi;
+            c.store_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, hi - lo, samples, seg_stride);
+        });
     return 0;
 }
+
+// usehashtable: calls are ordered by definition (each reads the file the previous one wrote), so they take turns
+std::mutex& hash_file_turn() { static std::mutex m; return m; }
 }  // namespace
 
 namespace {
@@ -112,6 +149,47 @@ std::string url_escape(const char* s) {
         else { o.push_back('%'); o.push_back(hex[*p >> 4]); o.push_back(hex[*p & 15]); }
     }
     return o;
+}
+}  // namespace
+
+namespace {
+// usehashtable on a batch: parallel decode against the shared, ordered hash memory (HashBatch), to the fixed point.
+// The memory of the calling thread's last such call is kept: WSPR_HASH_REVISIT decodes only what a new `prior` changes.
+thread_local std::unique_ptr<wspr::HashBatch> t_hash;
+static_assert(sizeof(wspr_hash_op) == sizeof(wspr::HashOp), "public and internal hash-op layouts differ");
+
+template <class Load, class Reload>
+int decode_hashed(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
+                  int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
+                  int seg_index0, const wspr_hash_op* prior, int n_prior, int flags, wspr_hash_op* stores_out, int cap,
+                  int* n_stores, int* n_redecoded) {
+    std::lock_guard<std::mutex> turn(hash_file_turn());
+    const bool revisit = (flags & WSPR_HASH_REVISIT) != 0;
+    if (revisit && !(t_hash && (int)t_hash->log.size() == nseg && t_hash->seg0 == seg_index0))
+        throw std::runtime_error("WSPR_HASH_REVISIT without a matching previous call on this thread");
+    if (!revisit) {
+        t_hash.reset(new wspr::HashBatch);
+        t_hash->load_file();
+        t_hash->seg0 = seg_index0;
+        t_hash->resize(nseg);
+    }
+    wspr::HashBatch& hb = *t_hash;
+    hb.rounds = hb.redecoded = 0;
+    hb.prior.assign(reinterpret_cast<const wspr::HashOp*>(prior), reinterpret_cast<const wspr::HashOp*>(prior) + std::max(0, n_prior));
+    std::stable_sort(hb.prior.begin(), hb.prior.end(), [](const wspr::HashOp& a, const wspr::HashOp& b) { return a.seg < b.seg; });
+    std::vector<int> todo;
+    if (revisit) { hb.rebuild(); todo = hb.invalid(); }
+    decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, writeback, idat, qdat, seg_stride,
+                 nullptr, &hb, revisit ? &todo : nullptr);
+    if (!(flags & WSPR_HASH_KEEP_FILE)) hb.commit_file();
+    const std::vector<wspr::HashOp> st = hb.stores();
+    if (n_stores) *n_stores = (int)st.size();
+    if (n_redecoded) *n_redecoded = hb.redecoded;
+    if (stores_out) {
+        if ((int)st.size() > cap) return -3;
+        memcpy(stores_out, st.data(), st.size() * sizeof(wspr::HashOp));
+    }
+    return 0;
 }
 }  // namespace
 
@@ -128,11 +206,9 @@ size_t wspr_iq_stride(void) { return (size_t)wspr::kIqStride; }
 int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results* decodes, int max_results,
                       int* n_results, int writeback) {
-    if (options.usehashtable && nseg > 1)
-        return decode_in_order(nseg, n_results, [&](int s) {
-            return wspr_decode_batch(idat + (size_t)s * seg_stride, qdat + (size_t)s * seg_stride, 1, samples, seg_stride,
-                                     options, decodes + (size_t)s * max_results, max_results, n_results + s, writeback);
-        });
+    if (options.usehashtable && nseg > 1)                 // the hash memory orders the segments: parallel all the same
+        return wspr_decode_batch_hashed(idat, qdat, nseg, samples, seg_stride, options, decodes, max_results, n_results,
+                                        writeback, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
     try {
         if (samples > wspr::kMaxSamples) {
             // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
@@ -153,6 +229,42 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return fail("wspr_decode_batch", e);
     }
+}
+
+int wspr_decode_batch_hashed(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
+                             struct decoder_options options, struct decoder_results* decodes, int max_results,
+                             int* n_results, int writeback, int seg_index0, const wspr_hash_op* prior, int n_prior,
+                             int flags, wspr_hash_op* stores_out, int cap, int* n_stores, int* n_redecoded) {
+    try {
+        if (samples > wspr::kMaxSamples) {
+            fprintf(stderr, "libwspr_mi355x: samples = %d exceeds the %d this library decodes\n", samples, wspr::kMaxSamples);
+            for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+            return -2;
+        }
+        options.usehashtable = 1;
+        return decode_hashed(nseg, samples, options, decodes, max_results, n_results,
+                             [&](Context& c, int lo, int n) {
+                                 c.load_host(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, n, samples, seg_stride);
+                             },
+                             [&](Context& c, int lo, const std::vector<int>& segs) {
+                                 c.reload_rows(idat + (size_t)lo * seg_stride, qdat + (size_t)lo * seg_stride, false, seg_stride, samples, segs);
+                             },
+                             writeback != 0, idat, qdat, seg_stride, seg_index0, prior, n_prior, flags, stores_out, cap,
+                             n_stores, n_redecoded);
+    } catch (const std::exception& e) {
+        if (!(flags & WSPR_HASH_REVISIT)) for (int s = 0; s < nseg; ++s) n_results[s] = 0;
+        return fail("wspr_decode_batch_hashed", e);
+    }
+}
+
+int wspr_hash_commit(const wspr_hash_op* stores, int n) {
+    try {
+        std::lock_guard<std::mutex> turn(hash_file_turn());
+        wspr::HashBatch hb;
+        hb.load_file();
+        wspr::HashBatch::commit_file(hb.base_call, hb.base_grid, reinterpret_cast<const wspr::HashOp*>(stores), (size_t)std::max(0, n));
+        return 0;
+    } catch (const std::exception& e) { return fail("wspr_hash_commit", e); }
 }
 
 int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
@@ -189,12 +301,6 @@ int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, siz
 int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results) {
-    if (options.usehashtable && nseg > 1)
-        return decode_in_order(nseg, n_results, [&](int s) {
-            return wspr_decode_batch_device(static_cast<const float*>(d_idat) + (size_t)s * seg_stride,
-                                            static_cast<const float*>(d_qdat) + (size_t)s * seg_stride, 1, samples, seg_stride,
-                                            options, decodes + (size_t)s * max_results, max_results, n_results + s);
-        });
     try {
         if (samples > wspr::kMaxSamples) {
             // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
@@ -205,18 +311,39 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
         }
         const float* di = static_cast<const float*>(d_idat);
         const float* dq = static_cast<const float*>(d_qdat);
-        return decode_split(nseg, samples, options, decodes, max_results, n_results,
-                            [&](Context& c, int lo, int n) {
-                                c.load_device(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, n, samples, seg_stride);
-                            },
-                            [&](Context& c, int lo, const std::vector<int>& segs) {
-                                c.reload_rows(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, true, seg_stride, samples, segs);
-                            },
-                            false, nullptr, nullptr, seg_stride);
+        auto load = [&](Context& c, int lo, int n) {
+            c.load_device(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, n, samples, seg_stride);
+        };
+        auto reload = [&](Context& c, int lo, const std::vector<int>& segs) {
+            c.reload_rows(di + (size_t)lo * seg_stride, dq + (size_t)lo * seg_stride, true, seg_stride, samples, segs);
+        };
+        if (options.usehashtable && nseg > 1)             // the hash memory orders the segments: parallel all the same
+            return decode_hashed(nseg, samples, options, decodes, max_results, n_results, load, reload, false, nullptr, nullptr,
+                                 seg_stride, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+        return decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, false, nullptr, nullptr, seg_stride);
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;
         return fail("wspr_decode_batch_device", e);
     }
+}
+
+// Pins caller memory for the host-buffer entry points (hipHostRegister without the caller needing HIP headers): the
+// reference's callers keep their I/Q buffers for the life of the process (rtlsdr_wsprd.c:78-90, 331-336), so they
+// pin them once and every wspr_decode*() call on them is a plain DMA.
+int wspr_pin_host_buffer(void* p, size_t bytes) {
+    if (!p || !bytes) return -1;
+    try { Context::get(); } catch (const std::exception& e) { return fail("wspr_pin_host_buffer", e); }
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess || e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return 0; }
+    fprintf(stderr, "libwspr_mi355x: wspr_pin_host_buffer: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return -1;
+}
+int wspr_unpin_host_buffer(void* p) {
+    if (!p) return -1;
+    const hipError_t e = hipHostUnregister(p);
+    (void)hipGetLastError();
+    return e == hipSuccess ? 0 : -1;
 }
 
 void wspr_shard_range(int nseg, int shard, int nshards, int* lo, int* hi) {
@@ -480,14 +607,14 @@ int wspr_last_timings(double* ms, int capacity) {
     // the calling thread's LAST batch call ran on (a capped or small call uses fewer than Context::slots(); contexts
     // are never created here)
     try {
-        double acc[16] = {0};
-        int n = 16;
+        double acc[24] = {0};
+        int n = 24;
         const int used = std::max(1, Context::last_slots_used());
         for (int g = 0; g < used; ++g) {
             Context* c = Context::slot_if_exists(g);
             if (!c) continue;
-            double t[16] = {0};
-            n = c->last_timings(t, 16);
+            double t[24] = {0};
+            n = c->last_timings(t, 24);
             for (int i = 0; i < n; ++i) acc[i] = (i < 7) ? (t[i] > acc[i] ? t[i] : acc[i]) : acc[i] + t[i];
         }
         n = n < capacity ? n : capacity;

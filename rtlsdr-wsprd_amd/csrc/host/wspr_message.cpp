@@ -5,6 +5,8 @@
 // the reference objects and against the CPU oracle).
 #include "wspr_message.h"
 
+#include <vector>
+
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -362,14 +364,34 @@ int unpack_prefix(int32_t nprefix, char* call) {
 
 namespace {
 inline bool legal_power(int dbm) { const int u = dbm % 10; return u == 0 || u == 3 || u == 7; }
-inline void remember(char* hashtab, const char* callsign) {
-    const uint32_t h = nhash15(callsign, std::strlen(callsign), 146u);
-    std::snprintf(hashtab + h * kHashWidth, kHashWidth, "%s", callsign);
-}
+// a look-up view whose answers are not recorded (see HashTable::peek)
+struct QuietView : HashTable {
+    HashTable& t;
+    explicit QuietView(HashTable& t_) : t(t_) {}
+    const char* call_at(int slot) override { return t.peek(slot); }
+    const char* peek(int slot) override { return t.peek(slot); }
+    void put(int slot, const char* call, const char* grid) override { t.put(slot, call, grid); }
+};
 }  // namespace
 
-// wsprd_utils.c:228-313.  Returns the reference's "noprint" flag.
+void FlatHashTable::put(int slot, const char* call, const char* grid) {
+    std::snprintf(hashtab + (size_t)slot * kHashWidth, kHashWidth, "%s", call);
+    if (grid) std::snprintf(loctab + (size_t)slot * kLocWidth, kLocWidth, "%s", grid);
+    if (dirty_vec) static_cast<std::vector<int>*>(dirty_vec)->push_back(slot);
+}
+
 int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* call_loc_pow,
+                   char* call, char* loc, char* pwr, char* callsign) {
+    FlatHashTable tab(hashtab, loctab);
+    return unpack_message(msg, tab, call_loc_pow, call, loc, pwr, callsign);
+}
+int channel_symbols(const char* text, char* hashtab, char* loctab, unsigned char* symbols) {
+    FlatHashTable tab(hashtab, loctab);
+    return channel_symbols(text, tab, symbols);
+}
+
+// wsprd_utils.c:228-313.  Returns the reference's "noprint" flag.
+int unpack_message(const signed char* msg, HashTable& tab, char* call_loc_pow,
                    char* call, char* loc, char* pwr, char* callsign) {
     int32_t n1, n2;
     unpack_50bits(msg, &n1, &n2);
@@ -386,9 +408,7 @@ int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* ca
         if (legal_power(ntype)) {                                  // type 1: CALL GRID dBm
             std::snprintf(dbm_txt, sizeof dbm_txt, "%02d", ntype);
             std::snprintf(call_loc_pow, 23, "%s %s %s", callsign, grid, dbm_txt);
-            const uint32_t h = nhash15(callsign, std::strlen(callsign), 146u);
-            std::snprintf(hashtab + h * kHashWidth, kHashWidth, "%s", callsign);
-            std::snprintf(loctab + h * kLocWidth, kLocWidth, "%s", grid);
+            tab.put((int)nhash15(callsign, std::strlen(callsign), 146u), callsign, grid);
             std::snprintf(call, kHashWidth, "%s", callsign);
             std::snprintf(loc, 7, "%s", grid);
             std::snprintf(pwr, 3, "%s", dbm_txt);
@@ -399,7 +419,7 @@ int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* ca
             const int dbm = ntype - nadd;
             std::snprintf(dbm_txt, sizeof dbm_txt, "%2d", dbm);
             std::snprintf(call_loc_pow, 23, "%s %s", callsign, dbm_txt);
-            if (legal_power(dbm)) remember(hashtab, callsign);
+            if (legal_power(dbm)) tab.put((int)nhash15(callsign, std::strlen(callsign), 146u), callsign, nullptr);
             else noprint = 1;
         }
     } else if (ntype < 0) {                                        // type 3: <hash> GRID6 dBm
@@ -413,8 +433,9 @@ int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* ca
             !std::isdigit(static_cast<unsigned char>(grid6[3])))
             noprint = 1;
         const int slot = (n2 - ntype - 64) / 128;
-        if (hashtab[slot * kHashWidth] != '\0')
-            std::snprintf(callsign, kHashWidth, "<%s>", hashtab + slot * kHashWidth);
+        const char* known = tab.call_at(slot);
+        if (known[0] != '\0')
+            std::snprintf(callsign, kHashWidth, "<%s>", known);
         else
             std::snprintf(callsign, kHashWidth, "<...>");
         std::snprintf(dbm_txt, sizeof dbm_txt, "%2d", dbm);
@@ -430,7 +451,7 @@ int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* ca
 // ---------------------------------------------------------------- channel symbols
 // wsprsim_utils.c:163-316: text -> 50 bits -> 162 convolutionally coded,
 // interleaved bits -> 4-FSK symbol = 2*bit + sync.
-int channel_symbols(const char* text, char* hashtab, char* loctab, unsigned char* symbols) {
+int channel_symbols(const char* text, HashTable& tab, unsigned char* symbols) {
     char buf[24];
     std::memset(buf, 0, sizeof buf);
     std::strncpy(buf, text, 22);
@@ -496,7 +517,8 @@ int channel_symbols(const char* text, char* hashtab, char* loctab, unsigned char
         signed char chk[11];
         std::memcpy(chk, data, sizeof chk);
         char a[23], b[13], c[13], d[7], e[3];
-        unpack_message(chk, hashtab, loctab, a, b, d, e, c);
+        QuietView quiet(tab);
+        unpack_message(chk, quiet, a, b, d, e, c);
     }
 
     unsigned char bits[176];

@@ -49,8 +49,34 @@ void unpack_50bits(const signed char* dat, int32_t* n1, int32_t* n2);
 int unpack_callsign(int32_t ncall, char* call);
 int unpack_grid(int32_t ngrid, char* grid);
 int unpack_prefix(int32_t nprefix, char* call);
+// What unpack_message() / channel_symbols() need of the callsign hash memory.  The reference keeps it in two flat arrays
+// local to wspr_decode (wsprd.c:478-479); a batch decoded with usehashtable shares one memory across segments in
+// index order and sees it through a view that logs what each segment looked up and stored (wspr_pipeline.h, HashBatch).
+struct HashTable {
+    virtual ~HashTable() {}
+    // callsign stored at `slot`, "" if none: the type-3 look-up of wsprd_utils.c:296-300
+    virtual const char* call_at(int slot) = 0;
+    // the same for a look-up whose answer is thrown away (the re-unpack inside channel_symbols, wsprsim_utils.c:280-300)
+    virtual const char* peek(int slot) = 0;
+    // type 1 (grid != nullptr): call and locator stored at `slot`; type 2 (grid == nullptr): the call alone
+    virtual void put(int slot, const char* call, const char* grid) = 0;
+};
+// the reference's own form: hashtab[32768][13], loctab[32768][5]; dirty (optional) collects the slots written
+struct FlatHashTable : HashTable {
+    char* hashtab;
+    char* loctab;
+    void* dirty_vec;            // std::vector<int>* or nullptr (kept opaque: this header stays free of <vector>)
+    FlatHashTable(char* h, char* l, void* dirty = nullptr) : hashtab(h), loctab(l), dirty_vec(dirty) {}
+    const char* call_at(int slot) override { return hashtab + (size_t)slot * kHashWidth; }
+    const char* peek(int slot) override { return hashtab + (size_t)slot * kHashWidth; }
+    void put(int slot, const char* call, const char* grid) override;
+};
+
+int unpack_message(const signed char* msg, HashTable& tab, char* call_loc_pow,
+                   char* call, char* loc, char* pwr, char* callsign);
 int unpack_message(const signed char* msg, char* hashtab, char* loctab, char* call_loc_pow,
                    char* call, char* loc, char* pwr, char* callsign);
+int channel_symbols(const char* text, HashTable& tab, unsigned char* symbols);
 int channel_symbols(const char* text, char* hashtab, char* loctab, unsigned char* symbols);
 
 }  // namespace wspr

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <mutex>
 #include <stdexcept>
@@ -38,6 +39,37 @@ namespace wspr {
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) +   \
                                      " at " #expr);                                          \
     } while (0)
+
+// ---------------------------------------------------------------- host waits --
+// How a host thread waits for its stream.  Measured in round 5 (tools/shard_cpu_profile.py): hipEventSynchronize() --
+// on events created with hipEventBlockingSync as well -- kept the waiting thread on a CPU for the whole wait in this
+// runtime (twelve lanes in flight = twelve CPUs busy doing nothing; a rank with two CPUs was host-bound at 77 % of the
+// GPU's rate on a single-signal batch).  The default is therefore a wait that costs no CPU: poll the event for a few
+// tens of microseconds (a small batch's kernels are done by then: single-call latency is unchanged), then sleep
+// between polls, with the sleep growing to a quarter of a millisecond.  WSPR_BLOCKING_SYNC=0: the runtime's spinning
+// wait; =1: the runtime's wait on blocking events (rounds 2-4); unset or =2: poll and sleep.
+static int wait_mode() {
+    static const int m = [] { const char* e = getenv("WSPR_BLOCKING_SYNC"); return e ? atoi(e) : 2; }();
+    return m;
+}
+static void host_wait(hipEvent_t ev) {
+    if (wait_mode() != 2) {
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventSynchronize");
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    long nap_ns = 20000;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventQuery");
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) { __builtin_ia32_pause(); continue; }
+        timespec ts{0, nap_ns};
+        nanosleep(&ts, nullptr);
+        nap_ns = std::min(nap_ns * 2, 250000L);
+    }
+}
 
 // ------------------------------------------------------------------ buffers --
 struct DevBuf {
@@ -166,6 +198,16 @@ private:
 };
 
 // ---------------------------------------------------------------- context ----
+namespace {
+struct SegBook {                 // host bookkeeping of one segment across passes
+    int   uniques = 0;
+    float allfreqs[100];
+    char  allcalls[100][13];
+    std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
+    std::vector<decoder_results> spots;   // every unique spot, in decode order (the reference's 100 at most)
+};
+}  // namespace
+
 struct Context::Impl {
     hipStream_t stream = nullptr;
     hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
@@ -176,17 +218,30 @@ struct Context::Impl {
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
         nvalid, decscratch, tabs, pw, pwfreq, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
+    // host-buffer entry (wspr_decode_batch: the reference's calling convention, wsprd.h:106-111): pageable caller rows
+    // are gathered into two pinned chunks in the working layout (rows of kIqStride floats, zero tail) that take turns,
+    // so that the host's gather of chunk k+1 runs under the DMA of chunk k and every DMA is one contiguous copy
+    PinBuf h_fz;                     // K6w's results on their way to the host (a copy into pageable memory would make
+                                     // the runtime wait for the search itself, on a CPU)
+    PinBuf h_stage[2];
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int stage_samples[2] = {0, 0};   // columns [samples, kIqStride) of a chunk are zero from here on
     int sub_flip = 0;
     bool dev_fano = false;           // this batch: Fano attempts on the device (see fano_device_mode())
     bool crowded = false;            // the previous batch had more than one Fano time-out per ten segments
     int cand_head = 16;              // candidates per segment copied to the host (adapts to the lists seen)
+    // host mirrors that keep their storage between calls: value-initialising 8 192 x 200 candidate slots (46 MB) and
+    // 8 192 segment books (14 MB) per call was a fifth of the host's CPU time per step on a single-signal batch
+    std::vector<DevCand> cand_host;
+    std::vector<int> npk_host;
+    std::vector<SegBook> books;
     std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
     std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
     int jitter_ladder[kMaxLags];
     // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
-    double t_ms[16] = {0};           // stage times (ms) and Fano statistics of the last batch
+    double t_ms[24] = {0};           // stage times (ms), Fano statistics and host CPU time by phase of the last batch
     std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0};
     bool blocking = false;
     hipEvent_t ev_sync = nullptr;
@@ -256,13 +311,13 @@ Context::Context(int nslots) : d(new Impl) {
     // Waiting host threads sleep on blocking events instead of spinning: never slower here (184 k vs
     // 180 k segments/s with 16 CPUs, 129 k vs 123 k with 2) and it leaves the CPUs to the Fano pools and
     // to other ranks.  WSPR_BLOCKING_SYNC=0 restores spinning.
-    const char* bs = getenv("WSPR_BLOCKING_SYNC");
-    d->blocking = bs ? atoi(bs) != 0 : true;
-    const unsigned evflags = d->blocking ? hipEventBlockingSync : hipEventDefault;
+    d->blocking = wait_mode() != 0;
+    const unsigned evflags = wait_mode() == 1 ? hipEventBlockingSync : hipEventDefault;
     HIP_OK(hipEventCreateWithFlags(&d->ev[0], evflags));
     HIP_OK(hipEventCreateWithFlags(&d->ev[1], evflags));
     HIP_OK(hipEventCreateWithFlags(&d->ev_sync, evflags | hipEventDisableTiming));
     for (auto& pr : d->ev_def) { HIP_OK(hipEventCreate(&pr[0])); HIP_OK(hipEventCreate(&pr[1])); }
+    for (auto& e : d->ev_stage) HIP_OK(hipEventCreateWithFlags(&e, evflags | hipEventDisableTiming));
 
     // constant tables, computed with the host libm exactly as the reference does
     std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
@@ -386,8 +441,9 @@ size_t Context::release_buffers() {
                               &c.fz_dat, &c.fz_steps, &c.fz_pool, &c.streamraw, &c.streamstate})
                 freed += b->release();
             for (PinBuf* b : {&c.h_npk, &c.h_cand, &c.h_items, &c.h_sync, &c.h_sym, &c.h_rms, &c.h_jobs, &c.h_jobs2, &c.h_seglist,
-                              &c.h_misc, &c.h_lists})
+                              &c.h_misc, &c.h_lists, &c.h_fz, &c.h_stage[0], &c.h_stage[1]})
                 b->release();
+            c.stage_samples[0] = c.stage_samples[1] = 0;
             free(c.hash_arena);
             c.hash_arena = nullptr;
             c.hash_arena_segs = 0;
@@ -412,12 +468,73 @@ static void zero_tail(float* wi, float* wq, int nseg, int samples, hipStream_t s
     HIP_OK(hipMemset2DAsync(wq + samples, (size_t)kIqStride * 4, 0, tail, nseg, st));
 }
 
+// Is this host address pinned (hipHostMalloc / hipHostRegister / wspr_pin_host_buffer)?  Pageable memory is "not
+// registered" (an error on older runtimes: cleared).
+static bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// One turnstile per device for the host-buffer loads: calls in flight on several lanes (and the slots of one call) take
+// the PCIe link one after the other instead of sharing it, so the first of them has its data -- and starts computing
+// under the others' transfers -- after 1/n of the time.
+static std::mutex& host_load_turn(int device) {
+    static std::mutex m[Context::kMaxDevices];
+    return m[std::max(0, std::min(device, Context::kMaxDevices - 1))];
+}
+
+// The reference's callers hand wspr_decode() HOST buffers (rtlsdr_wsprd.c:316, :689).  Pinned caller memory goes to
+// the device as one asynchronous strided copy per rail (DMA at the link's rate, no host work).  Pageable caller memory
+// would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows are gathered
+// (host pool) into this context's two pinned chunks, already in the working layout, and each chunk leaves as ONE
+// contiguous asynchronous copy per rail while the pool fills the other chunk.
 void Context::load_host(const float* I, const float* Q, int nseg, int samples, size_t stride) {
+    Impl& c = *d;
     float* wi = work_i(nseg);
     float* wq = work_q(nseg);
-    zero_tail(wi, wq, nseg, samples, d->stream);
-    HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, d->stream));
-    HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, d->stream));
+    if (nseg <= 0) return;
+    std::lock_guard<std::mutex> turn(host_load_turn(c.device));
+    if (host_is_pinned(I) && host_is_pinned(Q)) {
+        zero_tail(wi, wq, nseg, samples, c.stream);
+        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        return;
+    }
+    if (nseg < 16) {                                             // a single call's record or a handful: the runtime's own path
+        zero_tail(wi, wq, nseg, samples, c.stream);
+        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        return;
+    }
+    constexpr int chunk = 96;                                    // segments per chunk: 17.3 MB per rail, two rails, two chunks
+    const size_t row = (size_t)kIqStride, rail = (size_t)chunk * row;      // floats; the layout of a chunk never changes
+    for (int c0 = 0, k = 0; c0 < nseg; c0 += chunk, ++k) {
+        const int n = std::min(chunk, nseg - c0), b = k & 1;
+        const bool fresh = c.h_stage[b].cap < 2 * rail * 4;
+        float* st = static_cast<float*>(c.h_stage[b].need(2 * rail * 4));
+        if (fresh) { memset(st, 0, 2 * rail * 4); c.stage_samples[b] = 0; }
+        else if (k >= 2) host_wait(c.ev_stage[b]);                           // the DMA that read this chunk two turns ago
+        const int dirty = c.stage_samples[b];                    // a shorter record than the last one leaves old samples behind
+        auto fill = [&](int r) {
+            float* di = st + (size_t)r * row;
+            float* dq = st + rail + (size_t)r * row;
+            memcpy(di, I + (size_t)(c0 + r) * stride, (size_t)samples * 4);
+            memcpy(dq, Q + (size_t)(c0 + r) * stride, (size_t)samples * 4);
+            if (dirty > samples) {
+                memset(di + samples, 0, (size_t)(dirty - samples) * 4);
+                memset(dq + samples, 0, (size_t)(dirty - samples) * 4);
+            }
+        };
+        if (n >= 8) c.pool->run(n, fill, 2);
+        else for (int r = 0; r < n; ++r) fill(r);
+        // every row of the chunk now ends at `samples` (rows beyond n: whatever they held, never sent)
+        c.stage_samples[b] = (n == chunk) ? samples : std::max(dirty, samples);
+        HIP_OK(hipMemcpyAsync(wi + (size_t)c0 * row, st, (size_t)n * row * 4, hipMemcpyHostToDevice, c.stream));
+        HIP_OK(hipMemcpyAsync(wq + (size_t)c0 * row, st + rail, (size_t)n * row * 4, hipMemcpyHostToDevice, c.stream));
+        HIP_OK(hipEventRecord(c.ev_stage[b], c.stream));
+    }
+    // the chunks are read asynchronously; the caller's rows were consumed by the gather and may change from here on
 }
 void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {
     float* wi = work_i(nseg);
@@ -431,13 +548,13 @@ void Context::load_device(const void* dI, const void* dQ, int nseg, int samples,
 void Context::store_host(float* I, float* Q, int nseg, int samples, size_t stride) {
     HIP_OK(hipMemcpy2DAsync(I, stride * 4, d->iqI.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
     HIP_OK(hipMemcpy2DAsync(Q, stride * 4, d->iqQ.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
-    HIP_OK(hipStreamSynchronize(d->stream));
+    sync();
 }
 void Context::sync() {
     HIP_OK(hipGetLastError());
     if (d->blocking) {
         HIP_OK(hipEventRecord(d->ev_sync, d->stream));
-        HIP_OK(hipEventSynchronize(d->ev_sync));
+        host_wait(d->ev_sync);
     } else {
         HIP_OK(hipStreamSynchronize(d->stream));
     }
@@ -499,8 +616,8 @@ void Context::fetch_candidates_async(int nseg) {
 
 void Context::finish_fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
     Impl& c = *d;
-    npk.resize(nseg);
-    cand.resize((size_t)nseg * kMaxCand);
+    if (npk.size() < (size_t)nseg) npk.resize(nseg);
+    if (cand.size() < (size_t)nseg * kMaxCand) cand.resize((size_t)nseg * kMaxCand);    // entries beyond npk[s] are never read
     const int* h_npk = c.h_npk.as<int>();
     const DevCand* h_cand = c.h_cand.as<DevCand>();
     int longest = 0;
@@ -508,7 +625,7 @@ void Context::finish_fetch_candidates(int nseg, std::vector<int>& npk, std::vect
     const int head = c.cand_head;
     if (longest > head) {                                   // rare: fetch the full lists
         HIP_OK(hipMemcpyAsync(c.h_cand.p, c.cand.p, (size_t)nseg * kMaxCand * sizeof(DevCand), hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipStreamSynchronize(c.stream));
+        sync();
         memcpy(cand.data(), h_cand, (size_t)nseg * kMaxCand * sizeof(DevCand));
     } else {
         for (int s = 0; s < nseg; ++s)
@@ -536,20 +653,135 @@ void Context::finish_fetch_candidates(int nseg, std::vector<int>& npk, std::vect
 
 void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevCand>& cand) {
     fetch_candidates_async(nseg);
-    HIP_OK(hipStreamSynchronize(d->stream));
+    sync();
     finish_fetch_candidates(nseg, npk, cand);
 }
 
+// ------------------------------------------------------- batch hash memory ---
+HashBatch::HashBatch()
+    : base_call((size_t)kHashSlots * kHashWidth, 0), base_grid((size_t)kHashSlots * kLocWidth, 0), ver((size_t)kHashSlots) {}
+
+void HashBatch::load_file() {                                     // wsprd.c:481-494
+    std::fill(base_call.begin(), base_call.end(), 0);
+    std::fill(base_grid.begin(), base_grid.end(), 0);
+    if (FILE* fh = fopen("hashtable.txt", "r+")) {
+        char line[80], hcall[13], hgrid[5];
+        int nh;
+        while (fgets(line, sizeof line, fh) != nullptr) {
+            hgrid[0] = hcall[0] = '\0';
+            if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
+            if (nh >= 0 && nh < kHashSlots) {
+                snprintf(base_call.data() + (size_t)nh * kHashWidth, kHashWidth, "%s", hcall);
+                if (strlen(hgrid) > 0) snprintf(base_grid.data() + (size_t)nh * kLocWidth, kLocWidth, "%s", hgrid);
+            }
+        }
+        fclose(fh);
+    }
+}
+
+void HashBatch::rebuild() {
+    for (int slot : touched) ver[(size_t)slot].clear();
+    touched.clear();
+    auto add = [&](const HashOp& op) {
+        if (op.kind != 1 && op.kind != 2) return;
+        if (op.slot < 0 || op.slot >= kHashSlots) return;
+        auto& v = ver[(size_t)op.slot];
+        if (v.empty()) touched.push_back(op.slot);
+        if (v.empty() || v.back().seg != op.seg) v.emplace_back();
+        v.back().seg = op.seg;
+        memcpy(v.back().call, op.call, sizeof op.call);
+    };
+    // ascending segment order: the other shards' stores that precede this call, this call's, the ones that follow
+    size_t p = 0;
+    for (; p < prior.size() && prior[p].seg < seg0; ++p) add(prior[p]);
+    for (const auto& l : log) for (const HashOp& op : l) add(op);
+    for (; p < prior.size(); ++p) add(prior[p]);
+}
+
+const char* HashBatch::lookup(int slot, int gseg) const {
+    const auto& v = ver[(size_t)slot];
+    for (size_t i = v.size(); i-- > 0;)
+        if (v[i].seg < gseg) return v[i].call;
+    return base_call.data() + (size_t)slot * kHashWidth;
+}
+
+std::vector<int> HashBatch::invalid() const {
+    std::vector<int> out;
+    for (size_t s = 0; s < log.size(); ++s)
+        for (const HashOp& op : log[s])
+            if (op.kind == 3 && strcmp(lookup(op.slot, seg0 + (int)s), op.call) != 0) { out.push_back((int)s); break; }
+    return out;
+}
+
+std::vector<HashOp> HashBatch::stores() const {
+    std::vector<HashOp> out;
+    for (const auto& l : log) for (const HashOp& op : l) if (op.kind == 1 || op.kind == 2) out.push_back(op);
+    return out;
+}
+
+void HashBatch::commit_file(const std::vector<char>& call0, const std::vector<char>& grid0, const HashOp* w, size_t n) {
+    std::vector<char> call = call0, grid = grid0;
+    for (size_t i = 0; i < n; ++i) {
+        const HashOp& op = w[i];
+        if ((op.kind != 1 && op.kind != 2) || op.slot < 0 || op.slot >= kHashSlots) continue;
+        snprintf(call.data() + (size_t)op.slot * kHashWidth, kHashWidth, "%s", op.call);
+        if (op.kind == 1) snprintf(grid.data() + (size_t)op.slot * kLocWidth, kLocWidth, "%s", op.grid);
+    }
+    if (FILE* fh = fopen("hashtable.txt", "w")) {                 // wsprd.c:842-852
+        for (int i = 0; i < kHashSlots; ++i)
+            if (call[(size_t)i * kHashWidth] != '\0')
+                fprintf(fh, "%5d %s %s\n", i, call.data() + (size_t)i * kHashWidth, grid.data() + (size_t)i * kLocWidth);
+        fclose(fh);
+    }
+}
+
+void HashBatch::commit_file() const {
+    std::vector<HashOp> all;
+    size_t p = 0;
+    for (; p < prior.size() && prior[p].seg < seg0; ++p) all.push_back(prior[p]);
+    for (const HashOp& op : stores()) all.push_back(op);
+    for (; p < prior.size(); ++p) all.push_back(prior[p]);
+    commit_file(base_call, base_grid, all.data(), all.size());
+}
+
+namespace {
+// One segment's window on the batch's hash memory (see HashBatch): own stores first, then the predecessors', then the file.
+struct SegHashView : HashTable {
+    HashBatch& hb;
+    const int s;                                    // index within the call
+    char tmp[13];                                   // an own store's text, copied: the log may grow under the caller
+    SegHashView(HashBatch* hb_, int s_) : hb(*hb_), s(s_) {}
+    const char* own(int slot) {
+        const auto& l = hb.log[(size_t)s];
+        for (size_t i = l.size(); i-- > 0;)
+            if (l[i].slot == slot && (l[i].kind == 1 || l[i].kind == 2)) { memcpy(tmp, l[i].call, sizeof tmp); return tmp; }
+        return nullptr;
+    }
+    const char* peek(int slot) override {
+        if (const char* c = own(slot)) return c;
+        return hb.lookup(slot, hb.seg0 + s);
+    }
+    const char* call_at(int slot) override {
+        if (const char* c = own(slot)) return c;
+        const char* c = hb.lookup(slot, hb.seg0 + s);
+        HashOp op{};
+        op.seg = hb.seg0 + s; op.slot = slot; op.kind = 3;
+        snprintf(op.call, sizeof op.call, "%s", c);
+        hb.log[(size_t)s].push_back(op);
+        return c;                                   // base / version storage: unchanged for the whole round
+    }
+    void put(int slot, const char* call, const char* grid) override {
+        HashOp op{};
+        op.seg = hb.seg0 + s; op.slot = slot; op.kind = grid ? 1 : 2;
+        snprintf(op.call, sizeof op.call, "%s", call);
+        if (grid) snprintf(op.grid, sizeof op.grid, "%s", grid);
+        hb.log[(size_t)s].push_back(op);
+    }
+};
+}  // namespace
+
 // ---------------------------------------------------------------- decoding ---
 namespace {
-
-struct SegBook {                 // host bookkeeping of one segment across passes
-    int   uniques = 0;
-    float allfreqs[100];
-    char  allcalls[100][13];
-    std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
-    std::vector<decoder_results> spots;   // every unique spot, in decode order (the reference's 100 at most)
-};
 
 struct WaveItem {
     int seg, cand;
@@ -559,6 +791,19 @@ struct WaveItem {
     int  jitter = 0;
     unsigned cycles = 0;
     unsigned char decdata[11];
+};
+
+// CPU time of the calling thread (not wall time: a thread asleep in an event wait costs nothing) added to *acc
+struct CpuSpan {
+    double* acc;
+    double t0;
+    static double now_ms() {
+        timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    explicit CpuSpan(double* a) : acc(a), t0(now_ms()) {}
+    ~CpuSpan() { *acc += now_ms() - t0; }
 };
 
 struct Timer {
@@ -572,7 +817,7 @@ struct Timer {
     void stop() {
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(b, st));
-        HIP_OK(hipEventSynchronize(b));
+        host_wait(b);
         float ms = 0;
         HIP_OK(hipEventElapsedTime(&ms, a, b));
         *acc += ms;
@@ -630,13 +875,20 @@ std::atomic<unsigned>& fano_fast_budget() {
     return v;
 }
 
+int Context::decode_again(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
+                          int* n_results, const std::vector<int>& segs, HashBatch* hb, int hb_off) {
+    PendingFano none;
+    return decode_core(nseg, samples, opt, out, max_results, n_results, segs, 0u, none, nullptr, nullptr, hb, hb_off);
+}
+
 int Context::decode_resident(int nseg, int samples, const decoder_options& opt, decoder_results* out,
                              int max_results, int* n_results, const std::function<void(const std::vector<int>&)>& reload,
-                             wspr_trace* trace) {
+                             wspr_trace* trace, HashBatch* hb, int hb_off) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
     c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
+    CpuSpan cpu_all(&c.t_ms[16]);
     for (int s = 0; s < nseg; ++s) n_results[s] = 0;
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (nseg <= 0) return 0;
@@ -648,13 +900,15 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     const bool dev_fano = fano_device_mode() > 0 ||
                           (fano_device_mode() < 0 && nseg >= 256 && (rank_cpus() < 4 || d->crowded));
     // a traced decode runs every attempt with the full budget where it is first met (nothing provisional)
-    const unsigned fast = (reload && nseg >= 256 && !dev_fano && !trace) ? std::min(fast_cfg, 10000u) : 0u;
+    // (a shared hash memory keeps the host's full budget too: a provisional failure would log look-ups of a decode
+    // that is thrown away)
+    const unsigned fast = (reload && nseg >= 256 && !dev_fano && !trace && !hb) ? std::min(fast_cfg, 10000u) : 0u;
     if (trace) memset(trace, 0, (size_t)nseg * sizeof(wspr_trace));
     d->dev_fano = dev_fano;
     std::vector<int> all(nseg);
     for (int s = 0; s < nseg; ++s) all[s] = s;
     PendingFano pend;
-    decode_core(nseg, samples, opt, out, max_results, n_results, all, fast >= 10000u ? 0u : fast, pend, nullptr, trace);
+    decode_core(nseg, samples, opt, out, max_results, n_results, all, fast >= 10000u ? 0u : fast, pend, nullptr, trace, hb, hb_off);
     if (!pend.seg.empty()) {
         // ---- finish the provisional failures on the device, full budget ----------------------
         const auto t_t0 = std::chrono::steady_clock::now();
@@ -704,6 +958,8 @@ struct Context::DecodeRun {
     PendingFano& pend;
     const FanoMemo* memo = nullptr;           // results already known (re-decode after a late success)
     wspr_trace* trace = nullptr;              // per-candidate record of the fine search (wspr_decode_batch_trace)
+    HashBatch* hb = nullptr;                  // usehashtable on a batch: the shared, ordered hash memory ...
+    int hb_off = 0;                           // ... and this context's first segment in it
     struct ItemTrace {                        // one wave item's share of it, filled as the wave proceeds
         int m0_shift = 0; float m0_sync = 0; float sync0 = 0, rms0 = 0; int attempts = 0, fano_calls = 0;
         unsigned char sym0[kNSymD];
@@ -736,10 +992,10 @@ struct Context::DecodeRun {
     const int lagstep, nlag0, njit_rest;
     const FanoMetrics& met = default_metrics();
 
-    // per-segment state across passes
-    std::vector<SegBook> book;
-    std::vector<int> npk;
-    std::vector<DevCand> cand;
+    // per-segment state across passes (storage kept by the context between calls)
+    std::vector<SegBook>& book;
+    std::vector<int>& npk;
+    std::vector<DevCand>& cand;
     // per-pass state
     int ipass = 0;
     bool lockstep = false;
@@ -747,7 +1003,7 @@ struct Context::DecodeRun {
     std::vector<int> next_cand, win;
     // callsign hash memory: one zeroed table pair per segment, reused across batches
     const size_t per_seg = (size_t)kHashSlots * (kHashWidth + kLocWidth);
-    const bool persist;                       // hashtable.txt (single-segment calls only)
+    bool persist;                             // hashtable.txt read and written by THIS run (single-segment calls; a batch: HashBatch)
     // buffers of the current wave
     int n_shared = 0, n_own = 0;
     FineState *h_items = nullptr, *d_items = nullptr;
@@ -759,8 +1015,9 @@ struct Context::DecodeRun {
               unsigned fast_, PendingFano& pend_)
         : ctx(ctx_), c(*ctx_.d), nseg(nseg_), samples(samples_), opt(opt_), out(out_), max_results(max_results_),
           fast(fast_), pend(pend_), maxcycles(fast_ ? fast_ : 10000u), lagstep(opt_.quickmode ? 16 : 8),
-          nlag0(256 / (opt_.quickmode ? 16 : 8) + 1), njit_rest(opt_.quickmode ? 0 : kMaxLags - 1), book(nseg_),
-          persist(opt_.usehashtable && nseg_ == 1) {
+          nlag0(256 / (opt_.quickmode ? 16 : 8) + 1), njit_rest(opt_.quickmode ? 0 : kMaxLags - 1), book(ctx_.d->books),
+          npk(ctx_.d->npk_host), cand(ctx_.d->cand_host), persist(opt_.usehashtable && nseg_ == 1) {
+        if (book.size() < (size_t)nseg) book.resize((size_t)nseg);
         if (c.hash_arena_segs < (size_t)nseg) {
             free(c.hash_arena);
             c.hash_arena = static_cast<char*>(calloc((size_t)nseg, per_seg));
@@ -1215,11 +1472,15 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         for (int k = 0; k < 11; ++k) message[k] = (signed char)w.decdata[k];
         char callsign[13] = {0}, call_loc_pow[23] = {0}, call[13] = {0}, loc[7] = {0}, pwr[3] = {0};
         SegBook& bk = book[s];
-        const int noprint = unpack_message(message, hashtab_of(s), loctab_of(s), call_loc_pow, call, loc, pwr, callsign);
-        bk.dirty.push_back((int)nhash15(callsign, strlen(callsign), 146u));
+        // the segment's hash memory: its own zeroed tables (the reference's locals, wsprd.c:478-479; every slot written
+        // is noted and cleared again when the batch ends), or its window on the batch's shared memory (usehashtable)
+        FlatHashTable flat(hashtab_of(s), loctab_of(s), &bk.dirty);
+        std::unique_ptr<SegHashView> shared(hb ? new SegHashView(hb, hb_off + s) : nullptr);
+        HashTable& tab = hb ? static_cast<HashTable&>(*shared) : static_cast<HashTable&>(flat);
+        const int noprint = unpack_message(message, tab, call_loc_pow, call, loc, pwr, callsign);
         if (opt.subtraction && ipass == 0 && !noprint) {
             SubJob jb{};
-            if (channel_symbols(call_loc_pow, hashtab_of(s), loctab_of(s), jb.sym)) {
+            if (channel_symbols(call_loc_pow, tab, jb.sym)) {
                 jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
                 job_of[i] = jb;
                 has_job[i] = 1;
@@ -1325,11 +1586,16 @@ void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results)
 // records every attempt it could not finish in `pend` (see decode_resident).
 int Context::decode_core(int nseg, int samples, const decoder_options& opt, decoder_results* out, int max_results,
                          int* n_results, const std::vector<int>& active0, unsigned fast, PendingFano& pend,
-                         const FanoMemo* memo, wspr_trace* trace) {
+                         const FanoMemo* memo, wspr_trace* trace, HashBatch* hb, int hb_off) {
     for (int s : active0) n_results[s] = 0;
     DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
+    for (int s : active0) { SegBook& b = run.book[s]; b.uniques = 0; b.dirty.clear(); b.spots.clear(); }
     run.memo = memo;
     run.trace = trace;
+    run.hb = hb;
+    run.hb_off = hb_off;
+    if (hb) run.persist = false;
+    if (hb) for (int s : active0) hb->log[(size_t)(hb_off + s)].clear();      // a segment decoded again starts a new log
     // whatever happens below (a HIP error surfaces as an exception), the call signs this run wrote into the
     // context's hash memory must not survive into the next batch on this lane/slot
     struct HashGuard {
@@ -1349,22 +1615,25 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
             active.swap(keep);
         }
         if (active.empty()) break;
-        run.start_pass(ipass, active);
+        { CpuSpan sp(&d->t_ms[17]); run.start_pass(ipass, active); }
         for (;;) {
-            std::vector<WaveItem> wave = run.build_wave(active);
+            std::vector<WaveItem> wave;
+            { CpuSpan sp(&d->t_ms[18]); wave = run.build_wave(active); }
             if (wave.empty()) break;
-            run.refine_and_first_rung(wave);
-            run.remaining_rungs(wave);
-            run.subtract(run.keep_books(wave));
+            { CpuSpan sp(&d->t_ms[19]); run.refine_and_first_rung(wave); }
+            { CpuSpan sp(&d->t_ms[20]); run.remaining_rungs(wave); }
+            std::vector<SubJob> jobs;
+            { CpuSpan sp(&d->t_ms[21]); jobs = run.keep_books(wave); }
+            { CpuSpan sp(&d->t_ms[22]); run.subtract(jobs); }
         }
     }
-    run.finish(active0, n_results);
+    { CpuSpan sp(&d->t_ms[23]); run.finish(active0, n_results); }
     guard.armed = false;
     return 0;
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 16);
+    const int n = std::min(cap, 24);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }
@@ -1549,13 +1818,20 @@ int Context::fano_batch(const unsigned char* symbols, int n, unsigned maxcycles,
     upload(doff, h_off, (size_t)n * 4, c.stream);
     launch_fano_wave(dsym, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, dmet, dmax, ddat, dsteps,
                      static_cast<uint32_t*>(c.fz_pool.need(fano_wave_scratch_words(n) * 4)), c.stream);
-    HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(metric, dmet, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(maxnp, dmax, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
-    if (steps) HIP_OK(hipMemcpyAsync(steps, dsteps, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    char* hz = static_cast<char*>(c.h_fz.need((size_t)n * 30));
+    HIP_OK(hipMemcpyAsync(hz, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 4, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 8, dmet, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 12, dmax, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 16, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
+    if (steps) HIP_OK(hipMemcpyAsync(hz + (size_t)n * 26, dsteps, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
     sync();
+    memcpy(ret, hz, (size_t)n * 4);
+    memcpy(cycles, hz + (size_t)n * 4, (size_t)n * 4);
+    memcpy(metric, hz + (size_t)n * 8, (size_t)n * 4);
+    memcpy(maxnp, hz + (size_t)n * 12, (size_t)n * 4);
+    memcpy(data, hz + (size_t)n * 16, (size_t)n * 10);
+    if (steps) memcpy(steps, hz + (size_t)n * 26, (size_t)n * 4);
     {
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) if (ret[i] == -2) redo.push_back(i);
@@ -1590,10 +1866,14 @@ int Context::fano_resident(const unsigned char* d_symbols, const int* h_offsets,
     upload(doff, h_off, (size_t)n * 4, c.stream);
     launch_fano_wave(d_symbols, doff, n, c.t_metric0.as<short>(), maxcycles, dret, dcyc, nullptr, nullptr, ddat, nullptr,
                      static_cast<uint32_t*>(c.fz_pool.need(fano_wave_scratch_words(n) * 4)), c.stream);
-    HIP_OK(hipMemcpyAsync(ret, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(cycles, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipMemcpyAsync(data, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
+    char* hz = static_cast<char*>(c.h_fz.need((size_t)n * 18));
+    HIP_OK(hipMemcpyAsync(hz, dret, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 4, dcyc, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(hz + (size_t)n * 8, ddat, (size_t)n * 10, hipMemcpyDeviceToHost, c.stream));
     sync();
+    memcpy(ret, hz, (size_t)n * 4);
+    memcpy(cycles, hz + (size_t)n * 4, (size_t)n * 4);
+    memcpy(data, hz + (size_t)n * 8, (size_t)n * 10);
     const FanoMetrics& met = default_metrics();
     for (int i = 0; i < n; ++i) {
         if (ret[i] != -2) continue;
@@ -1730,7 +2010,12 @@ int Context::decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, 
     launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, st, d_states);
     if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, st);
     if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    if (c.blocking) {
+        HIP_OK(hipEventRecord(c.ev_sync, st));
+        host_wait(c.ev_sync);
+    } else {
+        HIP_OK(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -91,6 +91,98 @@ def decode_from_root(I, Q, nseg_total, samples, options, decode_shard, max_resul
     return gather_spots_sharded(out, cnt, nseg_total, max_results, record_size, dst=root)
 
 
+HASH_OP_BYTES = 32          # sizeof(wspr_hash_op), include/wspr_mi355x.h
+
+
+def hashed_rounds(decode_shard, commit=None):
+    """usehashtable = 1 over ranks WITHOUT taking turns (reference wsprd.c:481-494, 842-852).
+
+    The hash memory orders the segments, and the ranks hold contiguous shard_range() blocks, so rank r depends on what
+    ranks < r STORE -- nothing else.  Every rank decodes its block at once; the store logs (a few dozen 32-byte records
+    per segment at most) are exchanged; a rank whose predecessors' stores differ from what it last saw revisits its
+    block (the library decodes again only the segments whose look-ups would now be answered differently) and the
+    exchange repeats until no store list changes: rank r is final after round r + 1 at the latest, after one or two in
+    practice.  Then rank 0 applies all stores, in segment order, to hashtable.txt.
+
+    decode_shard(prior, revisit) -> stores: `prior` = uint8 array [n, 32] of the stores of all lower ranks in segment
+    order, `revisit` False on the first call; returns this rank's stores, uint8 [m, 32] (wspr_decode_batch_hashed with
+    WSPR_HASH_KEEP_FILE, plus WSPR_HASH_REVISIT when revisit).  commit(all_stores) runs on rank 0 (wspr_hash_commit).
+    Returns the number of rounds."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    empty = np.zeros((0, HASH_OP_BYTES), np.uint8)
+    stores = np.ascontiguousarray(decode_shard(empty, False), dtype=np.uint8).reshape(-1, HASH_OP_BYTES)
+    seen = empty.tobytes()
+    rounds = 1
+    while True:
+        every = [None] * world
+        dist.all_gather_object(every, stores.tobytes())
+        prior_bytes = b"".join(every[:rank])
+        changed = False
+        if prior_bytes != seen:
+            prior = np.frombuffer(prior_bytes, np.uint8).reshape(-1, HASH_OP_BYTES)
+            new = np.ascontiguousarray(decode_shard(prior, True), dtype=np.uint8).reshape(-1, HASH_OP_BYTES)
+            seen = prior_bytes
+            changed = new.tobytes() != stores.tobytes()
+            stores = new
+        flags = [None] * world
+        dist.all_gather_object(flags, changed)
+        if not any(flags):
+            break
+        rounds += 1
+        if rounds > world + 1:
+            raise RuntimeError("hashed_rounds: no fixed point after %d rounds (rank r is final after r + 1)" % rounds)
+    if rank == 0 and commit is not None:
+        commit(np.frombuffer(b"".join(every), np.uint8).reshape(-1, HASH_OP_BYTES))
+    dist.barrier()
+    return rounds
+
+
+def decode_batch_hashed_sharded(I, Q, nseg_total, options, max_results=16):
+    """The product under hashed_rounds(): this rank's shard_range() block of host rows I, Q ([n, samples] float32 numpy)
+    through wspr_decode_batch_hashed().  Returns (decoder_results ctypes array [n * max_results], int32 counts [n],
+    rounds).  Every rank must run in the same working directory as far as hashtable.txt is concerned only on rank 0
+    (the file is read by every rank, written by rank 0)."""
+    import rtlsdr_wsprd_amd as w
+    L = w.lib()
+    L.wspr_decode_batch_hashed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_hash_commit.argtypes = [C.c_void_p, C.c_int]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(nseg_total, rank, world)
+    n = hi - lo
+    I = np.ascontiguousarray(I, np.float32)
+    Q = np.ascontiguousarray(Q, np.float32)
+    assert I.shape[0] == n and Q.shape == I.shape
+    out = (w.decoder_results * (max(1, n) * max_results))()
+    cnt = (C.c_int * max(1, n))()
+    cap = 64 * n + 64
+    buf = np.zeros((cap, HASH_OP_BYTES), np.uint8)
+    opt = type(options).from_buffer_copy(bytes(options))
+    opt.usehashtable = 1
+
+    def decode_shard(prior, revisit):
+        if n == 0:
+            return np.zeros((0, HASH_OP_BYTES), np.uint8)
+        pr = np.ascontiguousarray(prior)
+        n_st = C.c_int(0)
+        rc = L.wspr_decode_batch_hashed(I.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), n, I.shape[1], I.shape[1], opt,
+                                        C.addressof(out), max_results, C.addressof(cnt), 0, lo,
+                                        pr.ctypes.data_as(C.c_void_p) if len(pr) else None, len(pr),
+                                        1 | (2 if revisit else 0), buf.ctypes.data_as(C.c_void_p), cap, C.byref(n_st), None)
+        if rc != 0:
+            raise RuntimeError("wspr_decode_batch_hashed failed (rc %d)" % rc)
+        return buf[:n_st.value].copy()
+
+    def commit(all_stores):
+        a = np.ascontiguousarray(all_stores)
+        if L.wspr_hash_commit(a.ctypes.data_as(C.c_void_p), len(a)) != 0:
+            raise RuntimeError("wspr_hash_commit failed")
+
+    rounds = hashed_rounds(decode_shard, commit)
+    return out, cnt, rounds
+
+
 def in_rank_order(fn):
     """Runs fn() on rank 0, then on rank 1, ... with a barrier between the turns, and returns this rank's result.
 
@@ -98,8 +190,9 @@ def in_rank_order(fn):
     hashtable.txt of the working directory, read before and written after every decode (wsprd.c:481-494, 842-852),
     so the result depends on the ORDER of the segments.  Ranks that share the working directory and take their
     turns in rank order over contiguous shards (shard_range) see the segments in global index order -- exactly what
-    one reference process walking all of them would produce.  There is nothing to parallelise in that mode; this
-    keeps the sharded driver correct for it."""
+    one reference process walking all of them would produce.  (Rounds 2-4 had nothing else for this mode; since round 5
+    hashed_rounds() / decode_batch_hashed_sharded() above reach the same result with every rank decoding at once.  This
+    stays as the plain fallback and for callers that want strict turns.)"""
     import os
     world, rank = dist.get_world_size(), dist.get_rank()
     # The turns only mean something if every rank reads and writes the SAME hashtable.txt.  Evidence of the same
@@ -186,6 +279,17 @@ def gather_spots(packed, dst=0):
     return torch.stack(bufs).cpu()
 
 
+def _wait_quietly(event):
+    """Waits for a torch.cuda.Event without holding a CPU: Event.synchronize() / Stream.synchronize() spin in this
+    runtime for as long as the GPU takes (a queue full of decoder kernels: milliseconds), on a CPU a rank with a small
+    share needs for its lanes."""
+    import time
+    nap = 50e-6
+    while not event.query():
+        time.sleep(nap)
+        nap = min(2 * nap, 500e-6)
+
+
 class SpotGatherer:
     """Per-step fan-in of spot records with preallocated buffers (no per-step allocation or host
     concatenation): the ctypes result arrays are viewed in place, copied to the device, gathered
@@ -219,7 +323,7 @@ class SpotGatherer:
         afterwards the decoder may be reused while exchange() runs."""
         # the previous exchange()'s host-to-device copies read these pinned buffers asynchronously
         if self._h2d_done is not None:
-            self._h2d_done.synchronize()
+            _wait_quietly(self._h2d_done)
         # plain memcpy through numpy views (a torch CPU copy would wake its intra-op thread pool)
         np.copyto(self._rec_stage_np, self._rec_src_np)
         np.copyto(self._cnt_stage_np, self._cnt_src_np)
@@ -243,7 +347,9 @@ class SpotGatherer:
             self.rec_host[r].copy_(self.rec_all[r], non_blocking=True)
             self.cnt_host[r].copy_(self.cnt_all[r], non_blocking=True)
         if self.nccl:
-            torch.cuda.current_stream().synchronize()
+            done = torch.cuda.Event()
+            done.record()
+            _wait_quietly(done)
         return self.cnt_host, self.rec_host
 
 

@@ -194,6 +194,153 @@ def test_world2_hashtable_segments_in_rank_order_through_the_product(tmp_path):
     _run_hashtable_world2(tmp_path, product=True)
 
 
+# ---- usehashtable over ranks without turns: hashed_rounds() ------------------------------------------------------
+def _op(seg, slot, kind, call):
+    a = np.zeros(32, np.uint8)
+    a[:12] = np.frombuffer(np.array([seg, slot, kind], np.int32).tobytes(), np.uint8)
+    b = call.encode()[:12]
+    a[12:12 + len(b)] = np.frombuffer(b, np.uint8)
+    return a
+
+
+def _script():
+    """A toy job of 9 'segments' over 3 ranks: each segment is a list of steps, ('put', slot, call) or ('get', slot).
+    A segment's output is what its gets see; if a get sees 'ZZ' the segment ALSO stores into slot 7 (its behaviour
+    depends on the look-up, as a decode's subtraction does)."""
+    return [[("put", 1, "AA")], [("get", 1)], [("put", 2, "BB")],
+            [("get", 2), ("put", 3, "ZZ")], [("get", 3)], [("get", 1), ("put", 1, "CC")],
+            [("get", 3), ("get", 7)], [("get", 1)], [("put", 2, "DD"), ("get", 2)]]
+
+
+def _run_segment(steps, table):
+    """-> (outputs, stores [(slot, call)]); table: slot -> call as the segment finds it"""
+    own, outs, stores = {}, [], []
+    for st in steps:
+        if st[0] == "put":
+            own[st[1]] = st[2]; stores.append((st[1], st[2]))
+        else:
+            v = own.get(st[1], table.get(st[1], ""))
+            outs.append(v)
+            if v == "ZZ":
+                own[7] = "QQ"; stores.append((7, "QQ"))
+    return outs, stores
+
+
+def _hr_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_wsprd_amd import dist as wd
+    script = _script()
+    lo, hi = wd.shard_range(len(script), rank, world)
+    result = {}
+    calls = []
+
+    def decode_shard(prior, revisit):
+        calls.append(revisit)
+        table = {}
+        for row in prior:                                   # the lower ranks' stores, in segment order
+            seg, slot, kind = np.frombuffer(row[:12].tobytes(), np.int32)
+            table[int(slot)] = bytes(row[12:25]).split(b"\0")[0].decode()
+        ops = []
+        for s in range(lo, hi):
+            outs, stores = _run_segment(script[s], table)
+            result[s] = outs
+            for slot, call in stores:
+                table[slot] = call
+                ops.append(_op(s, slot, 2, call))
+        return np.stack(ops) if ops else np.zeros((0, 32), np.uint8)
+
+    committed = []
+    rounds = wd.hashed_rounds(decode_shard, lambda allst: committed.append(allst.copy()))
+    every = [None] * world
+    dist.all_gather_object(every, (result, rounds, calls))
+    if rank == 0:
+        q.put((every, [(int(np.frombuffer(r[:4].tobytes(), np.int32)[0]), int(np.frombuffer(r[4:8].tobytes(), np.int32)[0]),
+                        bytes(r[12:25]).split(b"\0")[0].decode()) for r in committed[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world3_hashed_rounds_reach_the_serial_result():
+    """hashed_rounds() on CPU with a toy decoder whose behaviour depends on its look-ups: three gloo ranks, everybody
+    decodes at once, the stores are exchanged until they stop changing -- outputs and the committed store list are
+    those of one process walking the segments in order; rank 0 never revisits, nobody needs more than world + 1 rounds."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_hr_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    every, committed = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    script = _script()
+    table, want, want_stores = {}, {}, []
+    for s, steps in enumerate(script):
+        outs, stores = _run_segment(steps, table)
+        want[s] = outs
+        for slot, call in stores:
+            table[slot] = call
+            want_stores.append((s, slot, call))
+    got = {}
+    for result, rounds, calls in every:
+        got.update(result)
+    assert got == want
+    assert committed == want_stores
+    assert want[4] == ["ZZ"] and want[6] == ["ZZ", "QQ"] and want[7] == ["CC"]      # resolved across rank boundaries
+    assert every[0][2] == [False] and all(r[1] <= 4 for r in every)
+
+
+def _hs_worker(rank, world, port, q, workdir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.chdir(workdir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rtlsdr_wsprd_amd as w
+    from rtlsdr_wsprd_amd import dist as wd
+    segs = _ht_segments()
+    lo, hi = wd.shard_range(len(segs), rank, world)
+    I = np.stack([segs[s][0] for s in range(lo, hi)]); Q = np.stack([segs[s][1] for s in range(lo, hi)])
+    out, cnt, rounds = wd.decode_batch_hashed_sharded(I, Q, len(segs), w.default_options(), max_results=8)
+    mine = [sorted(out[i * 8 + k].message.split(b"\0")[0].decode() for k in range(cnt[i])) for i in range(hi - lo)]
+    allm = [None] * world
+    dist.all_gather_object(allm, (mine, rounds))
+    if rank == 0:
+        q.put(([m for part in allm for m in part[0]], [part[1] for part in allm]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world2_hashtable_without_turns_through_the_product(tmp_path):
+    """decode_batch_hashed_sharded(): two gloo ranks decode their shards AT ONCE with usehashtable (no in_rank_order
+    turns); spots and hashtable.txt equal those of the oracle walking the four segments in order."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shared = tmp_path / "ranks"; shared.mkdir()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_hs_worker, args=(r, 2, port, q, str(shared))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, rounds = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    alone = tmp_path / "alone"; alone.mkdir()
+    cwd = os.getcwd()
+    try:
+        os.chdir(alone)
+        ref = _ht_decode(_ht_segments(), 0, len(_HT_MSGS), False)
+        ref_file = open("hashtable.txt").read()
+    finally:
+        os.chdir(cwd)
+    assert got == ref and open(shared / "hashtable.txt").read() == ref_file
+    assert got[3] == ["<PJ4/K1ABC> FK52UD 37"] and rounds[0] >= 2
+
+
 # ---- real-input fan-out: rank 0 holds the IQ, the other ranks receive their rows (SURVEY 8e) -----------------
 def _root_worker(rank, world, port, q, product, nseg):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

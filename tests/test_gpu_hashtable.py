@@ -1,0 +1,201 @@
+"""usehashtable (-H) on a BATCH, decoded in parallel (reference wsprd.c:481-494, 842-852,
+wsprd_utils.c:264-311, wsprsim_utils.c:280-300).  The hash memory orders the segments; the product decodes them in parallel
+against a logged, versioned view of that memory and decodes again only the segments whose look-ups would have seen
+something else (wspr_pipeline.h, HashBatch).  Here: spots AND hashtable.txt of one batched call equal those of the oracle
+called segment by segment in index order, and of the product called segment by segment, on batches with 0 / 5 / 50 %
+type-2/3 traffic; the sharded form of the call (wspr_decode_batch_hashed with other shards' stores + wspr_hash_commit)
+gives the same again."""
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+pytestmark = pytest.mark.gpu
+NS = 45000
+
+# compound calls (type 2) and the 6-character locators their stations send in the hashed form (type 3)
+STATIONS = [("PJ4/K1ABC", "FK52UD", 37), ("K1ABC/7", "DN40AB", 30), ("VP9/W1AW", "FM72PH", 23), ("G4ABC/P", "IO91WM", 27),
+            ("F/DL0ABC", "JN18DU", 33), ("ZS6BKW/5", "KG33XX", 20), ("EA8/OH2AB", "IL18QI", 40), ("JA1XYZ/1", "PM95RR", 10)]
+
+
+@pytest.fixture(scope="module")
+def w():
+    import rtlsdr_wsprd_amd as mod
+    assert mod.lib().wspr_device_ready() == 1
+    return mod
+
+
+def _symbols(msg):
+    ok, s = ol.channel_symbols(msg)
+    assert ok, msg
+    return s
+
+
+def _traffic(nseg, frac23, seed, nsig=3, snr=-9.0):
+    """nseg segments of nsig signals; a signal is, with probability frac23, one of the compound-call stations, which
+    alternate between their type-2 and type-3 transmissions from segment to segment (as real stations do from slot to
+    slot) -- so a type-3 "<call>" usually resolves only through what an EARLIER segment of the batch stored."""
+    rng = np.random.default_rng(seed)
+    sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+    I = np.empty((nseg, NS), np.float32); Q = np.empty((nseg, NS), np.float32)
+    texts = []
+    for s in range(nseg):
+        i = rng.normal(0, sigma, NS); q = rng.normal(0, sigma, NS)
+        msgs = []
+        for k in range(nsig):
+            if rng.random() < frac23:
+                st = int(rng.integers(0, len(STATIONS)))
+                call, grid6, pwr = STATIONS[st]
+                m = ("%s %d" % (call, pwr)) if (s + st) % 2 == 0 else ("<%s> %s %d" % (call, grid6, pwr))
+            else:
+                m = synth.message_for(int(rng.integers(0, 1 << 20)))
+            msgs.append(m)
+            si, sq = synth.tone_signal(_symbols(m), -90.0 + 180.0 * k / max(1, nsig - 1) + rng.uniform(-3, 3),
+                                       2.0 + rng.uniform(-0.3, 0.3), 10.0 ** ((snr - 1.5 * k) / 20.0))
+            i += si; q += sq
+        I[s], Q[s] = synth.normalise(i.astype(np.float32), q.astype(np.float32))
+        texts.append(msgs)
+    return I, Q, texts
+
+
+def _tup(x):
+    return (x.message, x.call, x.loc, x.pwr, x.cycles, x.jitter, x.drift, x.sync, x.snr, x.dt, x.freq)
+
+
+def _opt(mod, use):
+    o = mod.default_options()
+    o.usehashtable = use
+    return o
+
+
+def _in_dir(d, fn):
+    cwd = os.getcwd()
+    d.mkdir()
+    os.chdir(d)
+    try:
+        out = fn()
+        txt = open("hashtable.txt").read() if os.path.exists("hashtable.txt") else ""
+        return out, txt
+    finally:
+        os.chdir(cwd)
+
+
+def _hashed(w, I, Q, seg0=0, prior=None, flags=0, out=None, nres=None, K=16):
+    """wspr_decode_batch_hashed through ctypes; returns (spots per segment, stores, n_redecoded, out, nres)."""
+    L = w.lib()
+    nseg = I.shape[0]
+    out = out if out is not None else (w.decoder_results * (nseg * K))()
+    nres = nres if nres is not None else (C.c_int * nseg)()
+    cap = 64 * nseg + 64
+    stores = np.zeros((cap, 32), np.uint8)
+    n_st = C.c_int(0); n_re = C.c_int(0)
+    pr = np.ascontiguousarray(prior if prior is not None else np.zeros((0, 32), np.uint8))
+    L.wspr_decode_batch_hashed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.wspr_decode_batch_hashed(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, _opt(w, 1), C.addressof(out), K, C.addressof(nres), 0,
+                                    seg0, ol.ptr(pr) if len(pr) else None, len(pr), flags, ol.ptr(stores), cap,
+                                    C.byref(n_st), C.byref(n_re))
+    assert rc == 0, rc
+    spots = [[_tup(out[s * K + i]) for i in range(nres[s])] for s in range(nseg)]
+    return spots, stores[:n_st.value].copy(), n_re.value, out, nres
+
+
+@pytest.mark.parametrize("frac23,nseg", [(0.0, 48), (0.05, 192), (0.5, 160)])
+def test_batch_with_hashtable_equals_the_serial_walk(w, tmp_path, frac23, nseg):
+    I, Q, texts = _traffic(nseg, frac23, 1000 + int(frac23 * 100))
+    n23 = sum(m.startswith("<") or "/" in m for seg in texts for m in seg)
+
+    def batch():
+        got = w.wspr_decode_batch(I, Q, _opt(w, 1), max_results=16)
+        return [[_tup(x) for x in g] for g in got]
+
+    def singles():
+        return [[_tup(x) for x in w.wspr_decode(I[s], Q[s], NS, _opt(w, 1))[0]] for s in range(nseg)]
+
+    def oracle():
+        o = ol.default_options()
+        o.usehashtable = 1
+        return [[_tup(x) for x in ol.decode(I[s], Q[s], NS, o)[0]] for s in range(nseg)]
+
+    b, bf = _in_dir(tmp_path / "batch", batch)
+    r, rf = _in_dir(tmp_path / "oracle", oracle)
+    strip = lambda res: [[t[:8] + t[9:] for t in seg] for seg in res]           # snr: host libm both, compared to 1e-4 below
+    assert strip(b) == strip(r)
+    assert all(abs(x[8] - y[8]) < 1e-4 for sb, sr in zip(b, r) for x, y in zip(sb, sr))
+    assert bf == rf
+    if nseg <= 64 or frac23 == 0.05:
+        s_, sf = _in_dir(tmp_path / "singles", singles)
+        assert s_ == b and sf == bf
+    msgs = [m.decode() for seg in b for (m, *_) in seg]
+    resolved = sum(m.startswith("<") and not m.startswith("<...>") for m in msgs)
+    unresolved = sum(m.startswith("<...>") for m in msgs)
+    # how much of the batch the ordered memory really touched: the direct call reports the segments decoded twice
+    (_, stores, n_re, _, _), hf = _in_dir(tmp_path / "hashed", lambda: _hashed(w, I, Q))
+    assert hf == bf
+    print("frac23 %.2f: %d segments, %d type-2/3 signals sent, %d resolved / %d unresolved type-3 spots, %d hash stores, "
+          "%d segments decoded again" % (frac23, nseg, n23, resolved, unresolved, len(stores), n_re))
+    if frac23 == 0.0:
+        assert n_re == 0 and resolved == 0
+    else:
+        assert resolved > 0 and n_re > 0
+    # a second pass over the same traffic in the SAME directory starts from the file the first one wrote: every look-up
+    # is answered by the file as its predecessors would answer it, nothing is decoded twice
+    if frac23 == 0.05:
+        def twice():
+            _hashed(w, I, Q)
+            return _hashed(w, I, Q)
+        (sp2, _, n_re2, _, _), _ = _in_dir(tmp_path / "twice", twice)
+        assert n_re2 == 0
+        assert sum(m.startswith(b"<...>") for seg in sp2 for (m, *_) in seg) == 0
+
+
+def test_sharded_hashed_calls_equal_one_batch(w, tmp_path):
+    """The protocol of a job sharded over several processes (include/wspr_mi355x.h, wspr_decode_batch_hashed), here with
+    three shards on three threads of one process: every shard decodes with no knowledge of the others, the stores are
+    exchanged, shards whose predecessors' stores changed revisit, one commit writes the file.  Same spots, same file."""
+    nseg = 150
+    I, Q, _ = _traffic(nseg, 0.3, 77)
+    whole, wf = _in_dir(tmp_path / "whole", lambda: [[_tup(x) for x in g] for g in w.wspr_decode_batch(I, Q, _opt(w, 1), max_results=16)])
+    L = w.lib()
+    bounds = [(0, 50), (50, 100), (100, 150)]
+    ranks = [ThreadPoolExecutor(1) for _ in bounds]
+    for k, ex in enumerate(ranks):
+        ex.submit(L.wspr_bind_thread_lane, 4 + k).result()
+
+    def job():
+        state = [None] * 3
+        stores = [np.zeros((0, 32), np.uint8)] * 3
+        seen_prior = [b""] * 3
+        rounds = 0
+        while True:
+            rounds += 1
+            changed = False
+            new_stores = list(stores)
+            for r, (lo, hi) in enumerate(bounds):
+                prior = np.concatenate(stores[:r]) if r else np.zeros((0, 32), np.uint8)
+                if state[r] is not None and prior.tobytes() == seen_prior[r]:
+                    continue
+                flags = 1 | (2 if state[r] is not None else 0)           # KEEP_FILE | REVISIT
+                out, nres = (state[r][3], state[r][4]) if state[r] is not None else (None, None)
+                state[r] = ranks[r].submit(_hashed, w, I[lo:hi], Q[lo:hi], lo, prior, flags, out, nres).result()
+                seen_prior[r] = prior.tobytes()
+                if state[r][1].tobytes() != stores[r].tobytes():
+                    changed = True
+                new_stores[r] = state[r][1]
+            stores = new_stores
+            if not changed:
+                break
+            assert rounds <= 4
+        allst = np.ascontiguousarray(np.concatenate(stores))
+        L.wspr_hash_commit.argtypes = [C.c_void_p, C.c_int]
+        assert L.wspr_hash_commit(ol.ptr(allst), len(allst)) == 0
+        return [sp for st in state for sp in st[0]], rounds
+    (sharded, rounds), sf = _in_dir(tmp_path / "sharded", job)
+    print("sharded -H: %d rounds" % rounds)
+    assert sharded == whole and sf == wf and rounds >= 2
