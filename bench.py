@@ -230,7 +230,7 @@ def measure_k1_traffic(nseg, nsig, timeout_s=150):
 
 
 def k0_report(L, m, with_cpu=True):
-    """Roofline of the front end (K0, the HBM-bound kernel of configs[4]) on the resident raw segments of measurement
+    """(L: the LAB library -- the timing and calibration entry points are not in the product.)  Roofline of the front end (K0, the HBM-bound kernel of configs[4]) on the resident raw segments of measurement
     `m`, HIP events on the launch stream, and the decimator's CPU baseline (the oracle's restatement of
     rtlsdr_callback(), rtlsdr_wsprd.c:126-244, over one whole 576 MB segment per host thread)."""
     raw, nraw = m["raw"], m["raw"].shape[0]
@@ -451,8 +451,6 @@ def main():
                          "per decoder call, default 1024, fed by front-end waves of --raw-segments)")
     ap.add_argument("--raw-segments", type=int, default=64,
                     help="--config 5: distinct raw segments resident in HBM (576 MB each) = one front-end wave")
-    ap.add_argument("--k0-cus", type=int, default=None,
-                    help="--config 5: CUs the front end may occupy (wspr_set_front_end_cus; 0 = all)")
     ap.add_argument("--cpu-share", type=int, default=None,
                     help="run as ONE rank of a job that gives each rank this many CPUs: the process is pinned to that many "
                          "CPUs (sched_setaffinity) and the library sizes its host side for them (WSPR_HOST_THREADS); "
@@ -537,10 +535,6 @@ def main():
         dist.all_gather_object(devs, my_dev)
     distinct_devices = len(set(devs))
     L = w.lib()
-    L.wspr_set_fano_fast_budget.restype = C.c_uint
-    L.wspr_release_buffers.restype = C.c_size_t
-    if args.k0_cus is not None:
-        L.wspr_set_front_end_cus(args.k0_cus)
 
     opt = w.default_options()
     if use_dist:
@@ -740,9 +734,12 @@ def main():
         I, Q = m["I"], m["Q"]
         roof = None
         if not args.no_kernel_roofline:
-            # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream
+            # ---- kernel-level roofline of the FFT+sync stage, HIP events on the launch stream.  The timing sets and the
+            # calibration kernels are entry points of the LAB library (include/wspr_mi355x_bench.h; the same kernels from
+            # the same sources: the product exports no benchmark); `value` above was measured on the product library.
+            LL = w.lab()
             ms = (C.c_double * 8)()
-            L.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 10, C.addressof(ms))
+            LL.wspr_bench_fft_sync(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), 20 if nseg <= 2048 else 10, C.addressof(ms))
             k1, k2, k3 = ms[0], ms[1], ms[2]
             traffic, traffic_src = None, None
             if world == 1 and not use_dist and not args.no_pmc and args.config in (2, 3, 4):
@@ -780,15 +777,15 @@ def main():
                                        "frac": STAGE_BYTES * nseg / ((k1 + k2 + k3) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
             # ---- the fp32-VALU-bound kernels: tiled lag scan (K4 mode 0), frequency scan + first rung, subtraction (K7)
             vms = (C.c_double * 8)()
-            L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
-            if L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 5, C.addressof(vms)) > 0 and vms[2] > 0:   # five timed passes after an untimed one
+            LL.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+            if LL.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), min(nseg, 2048), NS, I.stride(0), 5, C.addressof(vms)) > 0 and vms[2] > 0:   # five timed passes after an untimed one
                 def valu(flop_each, n, t_ms):
                     tf = flop_each * n / (t_ms * 1e-3) / 1e12
                     return {"avg_launch_ms": t_ms, "units": int(n), "achieved_TFs": tf, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
                             "frac_of_no_fma_bound": tf / VALU_NOFMA_TF}
                 mtf = C.c_double(0.0)
-                L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
-                L.wspr_calib_valu(20, C.addressof(mtf))
+                LL.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
+                LL.wspr_calib_valu(20, C.addressof(mtf))
                 roof["valu"] = {"peak_TFs": VALU_PEAK_TF, "no_fma_bound_TFs": VALU_NOFMA_TF,
                                 # register-only v_pk_mul_f32 + v_pk_add_f32 chains on every SIMD: the practical ceiling
                                 "measured_no_fma_TFs": mtf.value,
@@ -804,35 +801,35 @@ def main():
                 src = torch.empty(n_copy, device=dev, dtype=torch.float32).normal_()
                 dst = torch.empty_like(src)
                 torch.cuda.synchronize()
-                L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
+                LL.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 2)
                 t0 = time.perf_counter()
-                L.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
+                LL.wspr_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10)
                 roof["measured_copy_GBs"] = 10 * 8.0 * n_copy / (time.perf_counter() - t0) / 1e9
                 # the tuned copy (16 bytes per lane, four loads in flight per lane, resident grid), by cache policy: HIP events
-                L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+                LL.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
                 cms = C.c_double(0.0)
                 tuned = {}
                 for variant, name in ((0, "nontemporal_loads_and_stores"), (1, "nontemporal_stores"), (2, "default_policy")):
-                    L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, variant, None)
-                    L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, variant,
+                    LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, variant, None)
+                    LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, variant,
                                         C.addressof(cms))
                     tuned[name] = 8.0 * n_copy / (cms.value * 1e-3) / 1e9
                 roof["measured_copy16_GBs"] = max(tuned.values())            # the ceiling of mixed read + write traffic here
                 roof["measured_copy16_by_policy_GBs"] = tuned
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 3, None)
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 3, C.addressof(cms))
+                LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 3, None)
+                LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 3, C.addressof(cms))
                 roof["measured_write_only_GBs"] = 4.0 * n_copy / (cms.value * 1e-3) / 1e9
                 # ... and write-only in the spectrogram's pattern (64-byte pieces of 311 rows per group of 16 time blocks)
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 4, None)
-                L.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 4, C.addressof(cms))
+                LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 3, 4, None)
+                LL.wspr_calib_copy16(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n_copy), 10, 4, C.addressof(cms))
                 roof["measured_write_only_spectrogram_pattern_GBs"] = (n_copy // (417 * 352)) * 311 * 22 * 64 / (cms.value * 1e-3) / 1e9
                 rd = (C.c_double * 1)()                                       # read-only: K0's access pattern over the same bytes
-                L.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
+                LL.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
                 roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
                 del src, dst
         cpu = None
         if args.config == 5 and roof is not None:
-            roof["front_end_K0"] = k0_report(L, m, world == 1 and not args.no_cpu_baseline)
+            roof["front_end_K0"] = k0_report(w.lab(), m, world == 1 and not args.no_cpu_baseline)
             cpu = roof["front_end_K0"].pop("cpu_baseline", None)
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             cnt = min(nseg, 512)
@@ -863,7 +860,7 @@ def main():
                         "ms_per_step": m3["ms_per_step"], "batches_in_flight": m3["inflight"], "slots_per_batch": m3["slots"],
                         "seconds_timed": m3["elapsed"], "decoded_ok": m3["decoded_ok"],
                         "false_decodes": m3["false_decodes"], "stage_ms_last_step": m3["timings"],
-                        "front_end_K0": k0_report(L, m3, not args.no_cpu_baseline)}
+                        "front_end_K0": k0_report(w.lab(), m3, not args.no_cpu_baseline)}
             del m3
             torch.cuda.empty_cache()
         shard = None

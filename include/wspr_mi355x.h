@@ -6,6 +6,17 @@
  * linked against it instead of wsprd/wsprd.c.  Plain C
  * types only; device pointers are passed as void*.
  *
+ * This header is EVERYTHING libwspr_mi355x.so exports: the reference's symbols, their batched / resident / sharded
+ * forms, the front end, the receiver session, device selection and a few observability calls.  Stage-level parity
+ * hooks, the per-candidate trace, kernel timings and calibration kernels live in wspr_mi355x_bench.h and exist only
+ * in the lab build (libwspr_mi355x_lab.so, the same sources with -DWSPR_LAB), which is what the test suite and
+ * bench.py's kernel-level measurements load next to the product.
+ *
+ * Runtime knobs of the product (environment, read once): WSPR_HOST_THREADS (CPUs this process may count on: a
+ * rank's share), WSPR_SLOTS (pipelines per call, default 3), WSPR_BLOCKING_SYNC (how host threads wait: 2 = poll and
+ * sleep, default; 1 = runtime blocking events; 0 = spin), WSPR_FANO_DEVICE and WSPR_FANO_FAST (initial values of
+ * wspr_set_fano_device_mode() / wspr_set_fano_fast_budget()).  There are no others.
+ *
  * Every declaration cites the reference interface it replaces.
  * ==========================================================================*/
 #ifndef WSPR_MI355X_H
@@ -140,43 +151,6 @@ int wspr_decode_batch_device(const void *d_idat, const void *d_qdat, int nseg, i
                              size_t seg_stride, struct decoder_options options,
                              struct decoder_results *decodes, int max_results, int *n_results);
 
-/* Per-candidate trace of the fine search (the reference's candidate loop, wsprd.c:697-822): what the production
- * kernels -- lag scan, frequency scan fused with rung 0, the 43-lag ladder block, the Fano search -- produced for
- * EVERY candidate the loop entered, whether it decoded or not.  Same launches as wspr_decode_batch(); the only
- * differences are extra device-to-host copies and that the Fano budget split is off (every attempt runs the
- * reference's full budget where it is first met).  For parity tests against the oracle's trace. */
-#define WSPR_TRACE_PASSES 3
-typedef struct wspr_cand_trace {
-    int   visited;              /* the loop entered this candidate (it may have left the segment early, :786-793) */
-    int   mode0_shift;          /* after sync_and_demodulate(mode 0), wsprd.c:709-719 */
-    float mode0_sync;
-    float freq;                 /* after mode 1, :721-726: what the reference writes back to candidates[j] */
-    int   shift;
-    float drift;
-    float sync;
-    int   attempts;             /* mode-2 calls of the jitter ladder, :739-766 (0: sync <= minsync1) */
-    int   fano_calls;           /* of which passed the sync/rms gates (:759) and reached fano() */
-    float first_sync;           /* rung 0 of the ladder: sync, rms and the 162 soft symbols (transmission order) */
-    float first_rms;
-    int   decoded;
-    int   subtracted;
-    int   jitter;
-    unsigned cycles;
-    unsigned char first_symbols[162];
-    unsigned char decdata[11];
-    unsigned char pad[3];
-} wspr_cand_trace;
-typedef struct wspr_trace {
-    int passes_run;
-    int npk[WSPR_TRACE_PASSES];
-    int n_visited[WSPR_TRACE_PASSES];
-    wspr_cand_trace cand[WSPR_TRACE_PASSES][MAX_CANDIDATES];
-} wspr_trace;
-/* wspr_decode_batch() (host buffers, inputs untouched) that also fills trace[0..nseg). */
-int wspr_decode_batch_trace(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
-                            struct decoder_options options, struct decoder_results *decodes,
-                            int max_results, int *n_results, wspr_trace *trace);
-
 /* Node-level form (SURVEY §8e "one host process, 8 devices"): the nseg host segments are split into contiguous
  * blocks by wspr_shard_range() over `ndevices` HIP devices (0 = every visible device; more than are visible is an
  * error), one host thread per device, each block decoded by wspr_decode_batch() on its device straight into the
@@ -288,7 +262,7 @@ int wspr_format_wsprnet_url(const struct decoder_results *r, const struct decode
                             double dial_hz, int year, int month, int day, int hour, int minute,
                             const char *app_version, char *out, size_t cap);
 
-/* ---- kernel-level entry points (parity tests and profiling) --------------- */
+/* ---- the reference's other decoder entry points, GPU-backed ---------------- */
 /* Replaces sync_and_demodulate(), reference wsprd/wsprd.h:76-91 (GPU-backed).  symfac is honoured (mode 2,
  * wsprd.c:250); the decoder itself always passes 50. */
 void sync_and_demodulate(float *id, float *qd, long np, unsigned char *symbols, float *freq,
@@ -301,17 +275,6 @@ void subtract_signal(float *id, float *qd, long np, float f0, int shift, float d
 /* Replaces subtract_signal2(), reference wsprd/wsprd.h:99-105 (GPU-backed). */
 void subtract_signal2(float *id, float *qd, long np, float f0, int shift, float drift,
                       const unsigned char *channel_symbols);
-/* FFT bank + power spectrogram (reference wsprd/wsprd.c:509-553) for nseg host
- * segments; ps_out[s][bin 0..511][t 0..blocks) in the reference's bin-major
- * layout, bins outside 48..464 are zero. */
-int wspr_stage_fft_bank(const float *idat, const float *qdat, int nseg, int samples,
-                        size_t seg_stride, float *ps_out);
-/* Peak picker + coarse sync (reference wsprd/wsprd.c:555-678) for nseg host
- * segments: cand_out[s][200] strongest first (after coarse sync when coarse != 0),
- * npk_out[s], noise_out[s] (may be NULL), smspec_out[s][411] (may be NULL). */
-int wspr_stage_candidates(const float *idat, const float *qdat, int nseg, int samples,
-                          size_t seg_stride, int coarse, int maxdrift, struct cand *cand_out,
-                          int *npk_out, float *noise_out, float *smspec_out);
 /* Timing of the stages of the most recent batch call, milliseconds (HIP events on the library's
  * streams / host clock, summed over the slots).  Order: [0] FFT+sync stage, [1] host bookkeeping,
  * [2] device Fano tail (K6), [3] fine sync + demod, [4] subtract, [5] host Fano, [6] total wall time,
@@ -327,20 +290,6 @@ int wspr_last_timings(double *ms, int capacity);
  * not counted): what a rank adds to the host's load besides its callers -- 0 when its CPU share (WSPR_HOST_THREADS,
  * or the share of a node-level call) is no larger than the slots it drives. */
 int wspr_host_pool_workers(void);
-/* Times `iters` passes of the FFT+sync stage (K1,K2,K3) on resident data with HIP events on the
- * launch stream, after one untimed pass.  ms must hold 8 doubles: ms[0] = K1 (sum over the segment chunks of a pass),
- * ms[1] = K2 (time average of every chunk + peak picking), ms[2] = K3, ms[3] = K1 launches per
- * pass, ms[4] = wall time of one pass (first launch to last kernel end), all in milliseconds. */
-int wspr_bench_fft_sync(const void *d_idat, const void *d_qdat, int nseg, int samples,
-                        size_t seg_stride, int iters, double *ms);
-/* Times the two fp32-VALU-bound stages on resident data with HIP events on the launch stream: the
- * strongest candidate of every segment through the tiled lag scan (K4 mode 0, reference wsprd.c:709-719)
- * and the fused frequency scan + first ladder rung (wsprd.c:721-758), and one coherent subtraction
- * (K7, wsprd.c:316-413) per segment.  ms must hold 8 doubles: ms[0] = lag scan, ms[1] = subtraction,
- * ms[2] = candidates, ms[3] = subtraction jobs, ms[4] = frequency scan + first rung (milliseconds per
- * launch set, averaged over `iters` passes after one untimed pass, as wspr_bench_fft_sync does). */
-int wspr_bench_valu(const void *d_idat, const void *d_qdat, int nseg, int samples, size_t seg_stride,
-                    int iters, double *ms);
 /* Device Fano search (K6w) over n soft-symbol vectors of 162 bytes in transmission
  * (interleaved) order, i.e. deinterleave() + fano() of reference wsprd.c:759-761 (fano.c:87-238) with
  * delta 60: the exact wave-parallel search the decoder uses, one wavefront per vector (fano_wave.h).  Outputs per
@@ -387,31 +336,6 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
  * host threads or the pipeline's previous batch met more than one time-out per ten segments (a crowded band),
  * the host otherwise (single calls always).  Results are identical in every mode.  Returns the previous value. */
 int wspr_set_fano_device_mode(int mode);
-/* CUs the whole-segment front end (K0) may occupy: 0 = all (default; env WSPR_K0_CUS), else its kernels run on a
- * stream restricted to that many CUs (hipExtStreamCreateWithCUMask, spread over the XCDs), so that a decoder running
- * on another lane keeps the rest of the chip: K0 is HBM-bound and needs bandwidth, not every CU.  Returns the
- * previous value.  Results never depend on it. */
-int wspr_set_front_end_cus(int ncus);
-/* Times `iters` launches of the front end (K0 + normalise) on resident raw data with HIP events;
- * ms[0] = average milliseconds per launch. */
-int wspr_bench_decimate(const void *d_raw, size_t bytes_per_seg, int nseg, void *d_idat, void *d_qdat,
-                        int iters, double *ms);
-/* Read-bandwidth calibration for that roofline: `iters` launches of a kernel with K0's access pattern
- * (one workgroup per pair of CIC blocks, 16-byte non-temporal loads) and no arithmetic; ms[0] = average
- * milliseconds per launch over the same resident raw rows. */
-int wspr_calib_read(const void *d_raw, size_t bytes_per_seg, int nseg, int iters, double *ms);
-/* PMC calibration: `iters` launches of a 4-byte-per-lane stream copy of nfloats floats on the
- * library's stream (known traffic: 4*nfloats bytes read and written per launch). */
-int wspr_calib_copy(const void *d_src, void *d_dst, size_t nfloats, int iters);
-/* The tuned copy: 16 bytes per lane, four loads in flight per lane, resident grid (nfloats a multiple of 4, 16-byte
- * aligned buffers).  variant: 0 = non-temporal loads and stores, 1 = default loads + non-temporal stores, 2 = default
- * both, 3 = write only (d_dst is filled with 1.0f, d_src is not read).  ms (may be NULL) = average milliseconds per launch, HIP events on the launch stream. */
-int wspr_calib_copy16(const void *d_src, void *d_dst, size_t nfloats, int iters, int variant, double *ms);
-/* Vector-pipe calibration for the VALU rooflines: `launches` launches of register-only chains of separately
- * rounded packed multiplies and adds (v_pk_mul_f32 + v_pk_add_f32, no FMA) that fill every SIMD; *tflops =
- * sustained TFLOP/s (one flop per multiply or add), i.e. the practical ceiling of the decoder's arithmetic at the
- * clock the GPU holds under that load (theoretical: half of the fp32 FMA vector peak). */
-int wspr_calib_valu(int launches, double *tflops);
 /* Library / device description, e.g. for bench logs. */
 const char *wspr_mi355x_version(void);
 int wspr_device_ready(void);        /* 1 if a HIP device and the kernels are usable */

@@ -73,58 +73,90 @@ def build(verbose=False):
     subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], check=True, stdout=out, stderr=out)
 
 
+LAB_PATH = os.path.join(_HERE, "libwspr_mi355x_lab.so")
 _lib = None
+_lab = None
 
 
-def lib():
-    """Load libwspr_mi355x.so (raises if it has not been built)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libwspr_mi355x.so is not built: run rtlsdr-wsprd_amd/csrc/build.sh "
-                               "(there is no CPU fallback)")
-        L = C.CDLL(LIB_PATH)
-        L.wspr_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, decoder_options, C.c_void_p, C.c_void_p]
-        L.wspr_decode.restype = C.c_int
-        L.wspr_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, decoder_options,
-                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-        L.wspr_decode_batch.restype = C.c_int
-        L.wspr_decode_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
-                                               decoder_options, C.c_void_p, C.c_int, C.c_void_p]
-        L.wspr_decode_batch_device.restype = C.c_int
-        L.wspr_iq_stride.restype = C.c_size_t
-        L.wspr_mi355x_version.restype = C.c_char_p
-        L.wspr_device_ready.restype = C.c_int
+def _bind(path):
+    """CDLL + argument types of every entry point the library exports (the lab-only ones where present)."""
+    L = C.CDLL(path)
+    L.wspr_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, decoder_options, C.c_void_p, C.c_void_p]
+    L.wspr_decode.restype = C.c_int
+    L.wspr_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, decoder_options,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.wspr_decode_batch.restype = C.c_int
+    L.wspr_decode_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t,
+                                           decoder_options, C.c_void_p, C.c_int, C.c_void_p]
+    L.wspr_decode_batch_device.restype = C.c_int
+    L.wspr_iq_stride.restype = C.c_size_t
+    L.wspr_mi355x_version.restype = C.c_char_p
+    L.wspr_device_ready.restype = C.c_int
+    L.sync_and_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int]
+    L.sync_and_demodulate.restype = None
+    L.subtract_signal2.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_int, C.c_float, C.c_void_p]
+    L.subtract_signal2.restype = None
+    L.wspr_last_timings.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_decimate_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.wspr_decimate_u8_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.wspr_pin_host_buffer.argtypes = [C.c_void_p, C.c_size_t]
+    L.wspr_unpin_host_buffer.argtypes = [C.c_void_p]
+    L.wspr_release_buffers.restype = C.c_size_t
+    L.wspr_set_fano_fast_budget.restype = C.c_uint
+    L.nhash.restype = C.c_uint32
+    L.nhash.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+    L.pack_call.restype = C.c_ulong
+    L.pack_call.argtypes = [C.c_char_p]
+    L.pack_grid4_power.restype = C.c_ulong
+    L.get_callsign_character_code.restype = C.c_byte
+    L.get_locator_character_code.restype = C.c_byte
+    L.fano.restype = C.c_int
+    L.unpk_.restype = C.c_int
+    L.get_wspr_channel_symbols.restype = C.c_int
+    if hasattr(L, "wspr_stage_fft_bank"):            # include/wspr_mi355x_bench.h: the lab build only
         L.wspr_stage_fft_bank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.wspr_stage_fft_bank.restype = C.c_int
         L.wspr_stage_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wspr_stage_candidates.restype = C.c_int
-        L.sync_and_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                          C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                                          C.c_void_p, C.c_int]
-        L.sync_and_demodulate.restype = None
-        L.subtract_signal2.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_int, C.c_float, C.c_void_p]
-        L.subtract_signal2.restype = None
-        L.wspr_last_timings.argtypes = [C.c_void_p, C.c_int]
         L.wspr_bench_fft_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
-        L.wspr_decimate_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.wspr_decimate_u8_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
         L.wspr_bench_decimate.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.wspr_calib_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.wspr_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        L.nhash.restype = C.c_uint32
-        L.nhash.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
-        L.pack_call.restype = C.c_ulong
-        L.pack_call.argtypes = [C.c_char_p]
-        L.pack_grid4_power.restype = C.c_ulong
-        L.get_callsign_character_code.restype = C.c_byte
-        L.get_locator_character_code.restype = C.c_byte
-        L.fano.restype = C.c_int
-        L.unpk_.restype = C.c_int
-        L.get_wspr_channel_symbols.restype = C.c_int
-        _lib = L
+        L.wspr_calib_copy16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
+        L.wspr_decode_batch_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, decoder_options,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    return L
+
+
+def lib():
+    """The PRODUCT library, libwspr_mi355x.so (raises if it has not been built).  WSPR_USE_LAB=1 makes this the lab
+    library instead, for whole-suite runs of the lab build and for tests that need one of its environment switches."""
+    global _lib
+    if os.environ.get("WSPR_USE_LAB") == "1":
+        return lab()
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libwspr_mi355x.so is not built: run rtlsdr-wsprd_amd/csrc/build.sh "
+                               "(there is no CPU fallback)")
+        _lib = _bind(LIB_PATH)
     return _lib
+
+
+def lab():
+    """The LAB build of the same sources, libwspr_mi355x_lab.so: everything the product exports plus the stage-level
+    parity hooks, the per-candidate trace, kernel timings and calibration kernels of include/wspr_mi355x_bench.h.
+    A separate library with its own contexts and streams: tests and bench.py use it for those calls only."""
+    global _lab
+    if _lab is None:
+        if not os.path.exists(LAB_PATH):
+            raise RuntimeError("libwspr_mi355x_lab.so is not built: run rtlsdr-wsprd_amd/csrc/build.sh")
+        _lab = _bind(LAB_PATH)
+    return _lab
 
 
 def _ptr(a):
@@ -170,16 +202,15 @@ def wspr_decode_batch(I, Q, options=None, max_results=50):
 
 def wspr_decode_batch_trace(I, Q, options=None, max_results=50):
     """wspr_decode_batch() + the per-candidate trace of the fine search (what the production kernels produced for
-    every candidate the reference's loop enters).  Returns (spot lists, trace array [nseg])."""
+    every candidate the reference's loop enters), through the LAB library (include/wspr_mi355x_bench.h).
+    Returns (spot lists, trace array [nseg])."""
     I = np.ascontiguousarray(I, dtype=np.float32)
     Q = np.ascontiguousarray(Q, dtype=np.float32)
     nseg, samples = I.shape
     out = (decoder_results * (nseg * max_results))()
     nres = (C.c_int * nseg)()
     tr = (trace * nseg)()
-    L = lib()
-    L.wspr_decode_batch_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, decoder_options,
-                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L = lab()
     rc = L.wspr_decode_batch_trace(_ptr(I), _ptr(Q), nseg, samples, samples, options or default_options(),
                                    C.addressof(out), max_results, C.addressof(nres), C.addressof(tr))
     if rc < 0:

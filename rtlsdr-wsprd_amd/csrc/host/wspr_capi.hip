@@ -267,6 +267,7 @@ int wspr_hash_commit(const wspr_hash_op* stores, int n) {
     } catch (const std::exception& e) { return fail("wspr_hash_commit", e); }
 }
 
+#ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                             struct decoder_options options, struct decoder_results* decodes, int max_results,
                             int* n_results, wspr_trace* trace) {
@@ -297,6 +298,7 @@ int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, siz
         return fail("wspr_decode_batch_trace", e);
     }
 }
+#endif  // WSPR_LAB
 
 int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
@@ -397,7 +399,7 @@ int wspr_decode_batch_node(float* idat, float* qdat, int nseg, int samples, size
         return -1;
     }
     if (ndevices <= 0) ndevices = count;
-    const char* virt = getenv("WSPR_NODE_VIRTUAL");      // test hook: more shards than devices, folded onto lanes
+    const char* virt = wspr::lab_env("WSPR_NODE_VIRTUAL"); // test hook (lab build only): more shards than devices, folded onto lanes
     const int per_dev = (ndevices + count - 1) / count;
     if ((ndevices > count && !(virt && atoi(virt))) || ndevices > Context::kMaxDevices ||
         Context::lane() + per_dev > Context::kUserLanes) {
@@ -451,7 +453,7 @@ int wspr_decode_batch_node_device(const void* d_idat, const void* d_qdat, int sr
         return -1;
     }
     if (ndevices <= 0) ndevices = count;
-    const char* virt = getenv("WSPR_NODE_VIRTUAL");
+    const char* virt = wspr::lab_env("WSPR_NODE_VIRTUAL");
     const int per_dev = (ndevices + count - 1) / count;
     if ((ndevices > count && !(virt && atoi(virt))) || ndevices > Context::kMaxDevices ||
         Context::lane() + per_dev > Context::kUserLanes) {
@@ -550,6 +552,7 @@ void subtract_signal(float* id, float* qd, long np, float f0, int shift, float d
     catch (const std::exception& e) { fail("subtract_signal", e); }
 }
 
+#ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
                         float* ps_out) {
     try {
@@ -599,6 +602,7 @@ int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int sa
         return 0;
     } catch (const std::exception& e) { return fail("wspr_stage_candidates", e); }
 }
+#endif  // WSPR_LAB
 
 int wspr_host_pool_workers(void) { return wspr::pool_workers_alive().load(); }
 
@@ -623,6 +627,7 @@ int wspr_last_timings(double* ms, int capacity) {
     } catch (const std::exception& e) { return fail("wspr_last_timings", e); }
 }
 
+#ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,
                         double* ms) {
     try {
@@ -691,6 +696,7 @@ int wspr_calib_valu(int launches, double* tflops) {
         return 0;
     } catch (const std::exception& e) { return fail("wspr_calib_valu", e); }
 }
+#endif  // WSPR_LAB
 
 int wspr_device_count(void) {
     int n = 0;
@@ -730,9 +736,11 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit) {
     return wspr::fano_fast_budget().exchange(cycles_per_bit);
 }
 
+#ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_set_front_end_cus(int ncus) {
     return wspr::front_end_cus().exchange(ncus < 0 ? 0 : ncus);
 }
+#endif  // WSPR_LAB
 
 int wspr_set_fano_device_mode(int mode) {
     return wspr::fano_device_setting().exchange(mode < 0 ? -1 : (mode ? 1 : 0));
@@ -745,6 +753,7 @@ int wspr_fano_batch_device_wave(const unsigned char* symbols, int n, unsigned ma
     } catch (const std::exception& e) { return fail("wspr_fano_batch_device_wave", e); }
 }
 
+#ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat, int iters,
                         double* ms) {
     try {
@@ -757,6 +766,7 @@ int wspr_calib_read(const void* d_raw, size_t bytes_per_seg, int nseg, int iters
         return Context::get().bench_decimate(d_raw, bytes_per_seg, nseg, nullptr, nullptr, iters, ms);
     } catch (const std::exception& e) { return fail("wspr_calib_read", e); }
 }
+#endif  // WSPR_LAB
 
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {

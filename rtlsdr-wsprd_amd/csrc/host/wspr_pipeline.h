@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../../include/wspr_mi355x.h"
+#include "../../../include/wspr_mi355x_bench.h"   // declarations only: the definitions exist in the lab build (-DWSPR_LAB)
 #include "../kernels/wspr_device.h"
 
 namespace wspr {

@@ -52,6 +52,10 @@ static int wait_mode() {
     static const int m = [] { const char* e = getenv("WSPR_BLOCKING_SYNC"); return e ? atoi(e) : 2; }();
     return m;
 }
+// how long a wait polls before it starts sleeping: a single call's kernels finish within tens to hundreds of
+// microseconds and its latency is what its caller sees (one wspr_decode() per two minutes), a large batch's take
+// milliseconds and its lanes' CPUs are what the other lanes and ranks need
+static thread_local int t_spin_us = 40;
 static void host_wait(hipEvent_t ev) {
     if (wait_mode() != 2) {
         const hipError_t e = hipEventSynchronize(ev);
@@ -64,7 +68,7 @@ static void host_wait(hipEvent_t ev) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return;
         if (e != hipErrorNotReady) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventQuery");
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) { __builtin_ia32_pause(); continue; }
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(t_spin_us)) { __builtin_ia32_pause(); continue; }
         timespec ts{0, nap_ns};
         nanosleep(&ts, nullptr);
         nap_ns = std::min(nap_ns * 2, 250000L);
@@ -216,7 +220,7 @@ struct Context::Impl {
     DeviceTables tab{};
     DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
     DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, pwfreq, lists, scrsync, psavg, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
+        nvalid, decscratch, tabs, pw, pwfreq, lists, scrsync, psavg, densein, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
     PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
     // host-buffer entry (wspr_decode_batch: the reference's calling convention, wsprd.h:106-111): pageable caller rows
     // are gathered into two pinned chunks in the working layout (rows of kIqStride floats, zero tail) that take turns,
@@ -437,7 +441,7 @@ size_t Context::release_buffers() {
             if (c.fe_stream) HIP_OK(hipStreamSynchronize(c.fe_stream));
             for (DevBuf* b : {&c.iqI, &c.iqQ, &c.ps, &c.cand, &c.npk, &c.noise, &c.smspec, &c.seglist, &c.items, &c.syncbuf,
                               &c.symbuf, &c.rmsbuf, &c.jobs, &c.subscratch, &c.nvalid, &c.decscratch, &c.tabs, &c.pw, &c.pwfreq,
-                              &c.lists, &c.scrsync, &c.psavg, &c.fz_sym, &c.fz_off, &c.fz_ret, &c.fz_cyc, &c.fz_met, &c.fz_max,
+                              &c.lists, &c.scrsync, &c.psavg, &c.densein, &c.fz_sym, &c.fz_off, &c.fz_ret, &c.fz_cyc, &c.fz_met, &c.fz_max,
                               &c.fz_dat, &c.fz_steps, &c.fz_pool, &c.streamraw, &c.streamstate})
                 freed += b->release();
             for (PinBuf* b : {&c.h_npk, &c.h_cand, &c.h_items, &c.h_sync, &c.h_sym, &c.h_rms, &c.h_jobs, &c.h_jobs2, &c.h_seglist,
@@ -496,6 +500,25 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
     if (nseg <= 0) return;
     std::lock_guard<std::mutex> turn(host_load_turn(c.device));
     if (host_is_pinned(I) && host_is_pinned(Q)) {
+        // Pinned rows: LINEAR copies (the DMA engines at the link's rate, no CU involved) of up to kDense rows at a time
+        // into a dense device buffer, and the row kernel that also serves resident input spreads them into the working
+        // layout (device to device, microseconds).  A strided host-to-device copy straight into the working rows measured
+        // 40-45 GB/s against 55 for the linear one and cost the decoder kernels of the other lanes 10-15 % (round 5).
+        if ((samples & 3) == 0 && (stride & 3) == 0 && !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
+            constexpr int kDense = 512;
+            const int per = std::min(nseg, kDense);
+            float* dn = static_cast<float*>(c.densein.need((size_t)2 * per * stride * 4));
+            for (int c0 = 0; c0 < nseg; c0 += per) {
+                const int n = std::min(per, nseg - c0);
+                const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
+                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, c.stream));
+                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, c.stream));
+                if (!launch_load_rows(dn, dn + (size_t)per * stride, stride, samples, n, wi + (size_t)c0 * kIqStride,
+                                      wq + (size_t)c0 * kIqStride, c.stream))
+                    throw std::runtime_error("load_rows refused an aligned dense chunk");
+            }
+            return;
+        }
         zero_tail(wi, wq, nseg, samples, c.stream);
         HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
         HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
@@ -579,7 +602,7 @@ static void fft_and_average(const float* dI, const float* dQ, const int* d_segli
         HIP_OK(hipEventRecord(e, st));
         ev->push_back(e);
     };
-    static const int fused_cfg = [] { const char* e = getenv("WSPR_K1_FUSED"); return e ? atoi(e) : -1; }();
+    static const int fused_cfg = [] { const char* e = lab_env("WSPR_K1_FUSED"); return e ? atoi(e) : -1; }();
     const bool fused = fused_cfg < 0 ? nactive >= 256 : fused_cfg != 0;
     mark();
     if (fused) launch_fft_bank_avg(dI, dQ, d_seglist, nactive, samples, ps, psavg, tab, st);
@@ -889,6 +912,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     CpuSpan cpu_all(&c.t_ms[16]);
+    t_spin_us = nseg <= 16 ? 600 : 40;
     for (int s = 0; s < nseg; ++s) n_results[s] = 0;
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (nseg <= 0) return 0;
@@ -1638,6 +1662,7 @@ int Context::last_timings(double* ms, int cap) {
     return n;
 }
 
+#ifdef WSPR_LAB   // kernel-level timing sets (include/wspr_mi355x_bench.h): lab build only
 // average kernel durations of the FFT+sync stage, HIP events on the launch stream:
 // ms[0] = K1 (all chunks), ms[1] = K2 (time average of all chunks + peak picking), ms[2] = K3,
 // ms[3] = K1 launches per pass, ms[4] = wall time of the whole stage
@@ -1796,6 +1821,7 @@ int Context::bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, f
     (void)hipEventDestroy(e1);
     return 1;
 }
+#endif  // WSPR_LAB
 
 // Device Fano search over n host vectors: interleaved soft symbols in, results out.  The wave-parallel
 // kernel reports -2 for a vector whose pending-visit store overflowed (not seen in tests; the serial host
@@ -1972,7 +1998,7 @@ void Context::subtract_symbolwise_single(float* id, float* qd, long np, float f0
 // fall on different XCDs, so the share is spread over all eight and keeps every HBM stack busy), K0 still finds
 // the memory bandwidth it needs while the rest of the chip keeps computing.
 std::atomic<int>& front_end_cus() {
-    static std::atomic<int> v{[] { const char* e = getenv("WSPR_K0_CUS"); return e ? atoi(e) : 0; }()};
+    static std::atomic<int> v{[] { const char* e = lab_env("WSPR_K0_CUS"); return e ? atoi(e) : 0; }()};
     return v;
 }
 

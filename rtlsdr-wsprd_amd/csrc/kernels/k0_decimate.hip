@@ -261,59 +261,10 @@ __device__ __noinline__ void block_sum_vector_exact(const u4 q, const int n0, co
     }
 }
 
-__global__ __launch_bounds__(256)
-void cic_block_sums_fast_kernel(const uint8_t* __restrict__ raw, size_t bytes_per_seg, int nblocks,
-                                int32_t* __restrict__ sums) {
-    const int seg = blockIdx.y, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= nblocks) return;                                     // wave-uniform
-    const int lo = b * kR, hi = lo + kR;                          // the block's samples
-    const int vi_lo = (lo + 7) >> 3, vi_hi = hi >> 3;             // its interior vectors [vi_lo, vi_hi)
-    const int v_max = (int)((bytes_per_seg / 2 + 7) >> 3);        // vectors in a row
-    const u4* __restrict__ vec = reinterpret_cast<const u4*>(raw + (size_t)seg * bytes_per_seg);
-    unsigned acc[4] = {0u, 0u, 0u, 0u}, zacc[4] = {0u, 0u, 0u, 0u};
-    // software pipeline: the next round's four loads (and, under the last round, the masked round's one) are
-    // issued before the current round is consumed, so a wave always has 64-80 bytes per lane in flight
-    int vt = vi_lo + 768 + lane, k_lo = 0, k_hi = (vt < vi_hi) ? 8 : 0;
-    if (lane == 62) { vt = vi_lo - 1; k_lo = lo - 8 * vt; k_hi = (k_lo < 8) ? 8 : 0; }       // k_lo == 8: the block starts on a vector
-    if (lane == 63) { vt = vi_hi; k_hi = hi - 8 * vt; }                                      // 0: it ends on one
-    const u4* __restrict__ p0 = vec + vi_lo + lane;
-    u4 qa[4], qb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 64 * u);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) qb[u] = __builtin_nontemporal_load(p0 + 256 + 64 * u);
-    const int wb0 = kR + lo - 8 * (vi_lo + lane);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qa[u], wb0 - 512 * u, 0, 8, acc, zacc);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) qa[u] = __builtin_nontemporal_load(p0 + 512 + 64 * u);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qb[u], wb0 - 2048 - 512 * u, 0, 8, acc, zacc);
-    const u4 qt = __builtin_nontemporal_load(vec + min(max(vt, 0), v_max - 1));
-#pragma unroll
-    for (int u = 0; u < 4; ++u) block_sum_vector<false>(qa[u], wb0 - 4096 - 512 * u, 0, 8, acc, zacc);
-    block_sum_vector<true>(qt, kR + lo - 8 * vt, k_lo, k_hi, acc, zacc);
-    if (__any(((zacc[0] | zacc[1] | zacc[2] | zacc[3]) & 0x80808080u) != 0u)) {                      // clipping at the negative rail: exact path
-        acc[0] = acc[1] = acc[2] = acc[3] = 0u;
-        for (int v = vi_lo - 1 + lane; v <= vi_hi; v += 64) {
-            if (v < 0 || v >= v_max) continue;
-            const u4 q = __builtin_nontemporal_load(vec + v);
-            block_sum_vector_exact(q, 8 * v, lo, hi, acc);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned s = wave_sum(acc[i]);
-        if (lane == 0) sums[((size_t)seg * nblocks + b) * 4 + i] = (int32_t)s;
-    }
-}
-
 // ---- whole segments, block sums on the MATRIX pipe (round 4) -------------------------------------------------------
 // The block sums are int8 x int8 -> int32 contractions: S = sum_r (+-1 / 0) x_r,  W = sum_r (R - off_r)(+-1 / 0) x_r.
-// cic_block_sums_fast_kernel forms them with sixteen v_dot4_i32_i8 per 16-byte vector: 37 vector instructions per
-// vector, which is why the front end needs every CU's vector pipes to reach HBM's rate and cannot run beside the
-// decoder ("K0 and the decoder").  V_MFMA_I32_16X16X64_I8 takes the same contraction off the vector pipes:
+// Round 3's kernel (removed in round 5: it survived only behind a switch) formed them with sixteen v_dot4_i32_i8 per
+// 16-byte vector: 37 vector instructions per vector ("K0 and the decoder").  V_MFMA_I32_16X16X64_I8 takes the same contraction off the vector pipes:
 //   B (data)    lane l of a group of 64 consecutive vectors holds vector v0 + 64 g + l: column n = l & 15, k-block l >> 4;
 //   A (weights) row i = lane & 15, k-block lane >> 4, one weight per byte of a vector (tools/mfma_i8_probe.hip):
 //               row 0 / 1   the mixer's +-1 / 0 pattern for x_i / x_q              -> t   (sum over the column's vectors)
@@ -626,16 +577,12 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     uint32_t* x2 = reinterpret_cast<uint32_t*>(scratch + (size_t)nseg * nblocks * 4);
     // whole segments take the wave-per-block kernel (sample indices fit 31 bits: rows below 4 GiB);
     // WSPR_K0_KERNEL=general keeps them on the kernel that also serves carried states
-    static const bool general = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'g'; }();
-    // WSPR_K0_KERNEL=dot4: whole segments on the vector-pipe kernel (sixteen v_dot4 per vector) instead of the MFMA one
-    static const bool dot4 = [] { const char* e = getenv("WSPR_K0_KERNEL"); return e && e[0] == 'd'; }();
+    // (lab build only)
+    static const bool general = [] { const char* e = lab_env("WSPR_K0_KERNEL"); return e && e[0] == 'g'; }();
     if (!states && !general && bytes_per_seg < ((size_t)1 << 32)) {
-        if (dot4)
-            hipLaunchKernelGGL(cic_block_sums_fast_kernel, dim3((nblocks + 3) / 4, nseg), dim3(256), 0, st, raw,
-                               bytes_per_seg, nblocks, sums);
-        else {
-            // WSPR_K0_RESIDENT=p: a resident grid of p workgroups per CU instead of one workgroup per four blocks
-            static const int per_cu = [] { const char* e = getenv("WSPR_K0_RESIDENT"); return e ? atoi(e) : 0; }();
+        {
+            // WSPR_K0_RESIDENT=p (lab build only): a resident grid of p workgroups per CU instead of one workgroup per four blocks
+            static const int per_cu = [] { const char* e = lab_env("WSPR_K0_RESIDENT"); return e ? atoi(e) : 0; }();
             const int quads = (nblocks + 3) / 4;
             if (per_cu > 0 && nseg > 1 && (long)quads * nseg > 256L * per_cu)
                 hipLaunchKernelGGL(cic_block_sums_mfma_kernel, dim3(256 * per_cu, 1), dim3(256), 0, st, raw, bytes_per_seg,
@@ -656,6 +603,7 @@ void launch_decimate(const uint8_t* raw, size_t bytes_per_seg, int nseg, float* 
     if (states) hipLaunchKernelGGL(cic_carry_kernel, dim3(nseg), dim3(128), 0, st, x2, nblocks, nsamp, states);
 }
 
+#ifdef WSPR_LAB   // calibration kernel: lab build only
 // Calibration for K0's roofline: the same read pattern as cic_block_sums_kernel (one workgroup per 12 802
 // bytes of a row, aligned 16-byte non-temporal loads, four in flight per lane) with one add per dword instead
 // of the mixer and block-sum arithmetic -- what the memory system delivers to a read-only stream of this shape.
@@ -687,5 +635,6 @@ void launch_calib_read(const uint8_t* raw, size_t bytes_per_seg, int nseg, unsig
     if (nseg <= 0 || nblocks <= 0) return;
     hipLaunchKernelGGL(calib_read_kernel, dim3((nblocks + 1) / 2, nseg), dim3(256), 0, st, raw, bytes_per_seg, nblocks, out);
 }
+#endif  // WSPR_LAB
 
 }  // namespace wspr

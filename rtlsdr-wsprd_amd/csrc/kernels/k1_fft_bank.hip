@@ -506,6 +506,7 @@ void fft_bank_avg_kernel(const float* __restrict__ dI, const float* __restrict__
 
 }  // namespace
 
+#ifdef WSPR_LAB   // calibration kernels: lab build only
 // Calibration helper for the HBM PMC counters: a plain 4-byte-per-lane stream copy, the
 // same access width as K1's loads/stores, over a known number of bytes.
 namespace {
@@ -581,6 +582,7 @@ void launch_calib_copy16(const float* src, float* dst, size_t n, hipStream_t st,
     else if (variant == 1) hipLaunchKernelGGL(calib_copy16_kernel<1>, grid, block, 0, st, s4, d4, n / 4);
     else hipLaunchKernelGGL(calib_copy16_kernel<2>, grid, block, 0, st, s4, d4, n / 4);
 }
+#endif  // WSPR_LAB
 
 void launch_fft_bank(const float* dI, const float* dQ, const int* seg_list, int nseg_active,
                      int samples, float* ps, const DeviceTables& t, hipStream_t st) {

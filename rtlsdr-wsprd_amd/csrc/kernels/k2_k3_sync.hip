@@ -637,7 +637,7 @@ void launch_coarse_sync(const float* ps, const int* seg_list, int nseg_active, i
     // Full-length records of large batches take the lane-per-(candidate, lag) kernel: its single-wave workgroups
     // pay two staging round trips each, which a launch of a few hundred candidate pairs cannot hide (1 024
     // single-signal segments: 59 vs 46 us; 8 192 x 10 signals: 0.93 vs 1.15 ms).  WSPR_K3_KERNEL=waves / lane force one.
-    static const int forced = [] { const char* e = getenv("WSPR_K3_KERNEL"); return !e ? 0 : (e[0] == 'w' ? 1 : 2); }();
+    static const int forced = [] { const char* e = lab_env("WSPR_K3_KERNEL"); return !e ? 0 : (e[0] == 'w' ? 1 : 2); }();
     const bool lane_kernel = forced ? forced == 2 : nseg_active >= 1536;
     if (blocks == kMaxBlocks && lane_kernel)
         hipLaunchKernelGGL(coarse_sync_lane_kernel, dim3(nseg_active, gy), dim3(64), 0, st, ps, seg_list, cand, npk,

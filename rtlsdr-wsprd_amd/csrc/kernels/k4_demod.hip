@@ -1120,9 +1120,9 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     const float4* pl = reinterpret_cast<const float4*>(pw_lag);
     // WSPR_REPEAT_FREQ / _LAG / _FANO = 2: the stage's kernels are launched twice (same outputs) -- what a stage costs
     // INSIDE the pipelined step is the difference of two bench lines
-    static const int rep_freq = [] { const char* e = getenv("WSPR_REPEAT_FREQ"); return e ? atoi(e) : 1; }();
+    static const int rep_freq = [] { const char* e = lab_env("WSPR_REPEAT_FREQ"); return e ? std::max(1, atoi(e)) : 1; }();
     // WSPR_K4_FREQ=nocentre: no centre hypothesis is taken from the lag scan (every candidate through the rare path)
-    static const bool nocentre = [] { const char* e = getenv("WSPR_K4_FREQ"); return e && e[0] == 'n'; }();
+    static const bool nocentre = [] { const char* e = lab_env("WSPR_K4_FREQ"); return e && e[0] == 'n'; }();
     const int nlag_c = (pl && !nocentre) ? nlag_lag : 0;
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
@@ -1136,7 +1136,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
                            sync_out, sym_out, rms_out, t.sync);
     }
     if (n_own > 0) {
-        static const bool general = [] { const char* e = getenv("WSPR_K4_DRIFT"); return e && e[0] == 't'; }();
+        static const bool general = [] { const char* e = lab_env("WSPR_K4_DRIFT"); return e && e[0] == 't'; }();
         if (!general) {
             // pw rows of the drifting candidates follow those of the drift-free ones
             float4* pw_own = reinterpret_cast<float4*>(pw) + (size_t)n_shared * kNFreq * kNSymD;
@@ -1179,10 +1179,10 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
     float4* pw4 = reinterpret_cast<float4*>(pw);
     // WSPR_K4_LAG=tile: drift-free candidates' full lag scan on demod_tile_kernel<8, true> (one (symbol, lag) per lane,
     // samples in LDS) instead of the register-resident correlation
-    static const bool lagsys_kernel = [] { const char* e = getenv("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
+    static const bool lagsys_kernel = [] { const char* e = lab_env("WSPR_K4_LAG"); return !(e && e[0] == 't'); }();
     // WSPR_K4_DRIFT=tile: drifting candidates' full lag scan on demod_tile_kernel<8, false> (one lag per lane)
-    static const bool drift_kernel = [] { const char* e = getenv("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
-    static const int rep_lag = [] { const char* e = getenv("WSPR_REPEAT_LAG"); return e ? atoi(e) : 1; }();
+    static const bool drift_kernel = [] { const char* e = lab_env("WSPR_K4_DRIFT"); return !(e && e[0] == 't'); }();
+    static const int rep_lag = [] { const char* e = lab_env("WSPR_REPEAT_LAG"); return e ? std::max(1, atoi(e)) : 1; }();
 #define WSPR_LAUNCH_TILE(STEP)                                                                                   \
     do {                                                                                                         \
         if (n_shared > 0 && STEP == 8 && nlag == 33 && mode == 0 && lagsys_kernel)                               \
@@ -1210,6 +1210,7 @@ void launch_demod_tiled(const float* dI, const float* dQ, int samples, const Fin
                        mode, nlag, minsync1, sync_out, sym_out, rms_out, t.sync);
 }
 
+#ifdef WSPR_LAB   // calibration kernel: lab build only
 // Calibration for the vector rooflines: register-only chains of separately rounded packed multiplies and adds
 // (the instruction mix of the matched-filter sums, nothing else), enough waves to fill every SIMD.  What it
 // sustains is the practical ceiling of v_pk_mul_f32 / v_pk_add_f32 at the clock the GPU holds under this load.
@@ -1241,6 +1242,7 @@ double launch_calib_valu(float* out, int iters, hipStream_t st) {
     hipLaunchKernelGGL(calib_valu_kernel, dim3(wgs), dim3(256), 0, st, out, iters);
     return (double)wgs * 256 * iters * 8 * 8 * 4;  // 8 x 8 (mul + add) pairs of 2 lanes-halves
 }
+#endif  // WSPR_LAB
 
 void launch_pick_lag(FineState* items, int nitems, const float* sync_in, int nlag, int lagstep, hipStream_t st) {
     if (nitems <= 0) return;

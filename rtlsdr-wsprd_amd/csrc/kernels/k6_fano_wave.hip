@@ -265,7 +265,7 @@ void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, c
     if (n <= 0) return;
     const int grid = std::min(n, kWaveGrid);
     int* counter = reinterpret_cast<int*>(scratch + (size_t)grid * 5 * 4096);
-    static const int rep = [] { const char* e = getenv("WSPR_REPEAT_FANO"); return e ? atoi(e) : 1; }();
+    static const int rep = [] { const char* e = lab_env("WSPR_REPEAT_FANO"); return e ? atoi(e) : 1; }();
     for (int r = 1; r < rep; ++r) {                       // measurement hook: the same launch again (same outputs)
         (void)hipMemsetAsync(counter, 0, sizeof(int), st);
         hipLaunchKernelGGL((fano_wave_kernel<4096>), dim3(grid), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
@@ -275,7 +275,7 @@ void launch_fano_wave(const unsigned char* symbols, const int* offsets, int n, c
     // WSPR_FANO_WAVE_CAP=1024 (test hook, tests/test_gpu_parity.py): a stack of 1 024 visits instead of 4 096, so that the
     // narrowed steps (8 visits, then 1, as the stack fills), the window's spills and fills at those widths and the
     // overflow exit (-2: the caller's host routine takes the vector) are exercised by ordinary time-out vectors
-    static const bool small = [] { const char* e = getenv("WSPR_FANO_WAVE_CAP"); return e && atoi(e) == 1024; }();
+    static const bool small = [] { const char* e = lab_env("WSPR_FANO_WAVE_CAP"); return e && atoi(e) == 1024; }();
     if (small)
         hipLaunchKernelGGL((fano_wave_kernel<1024>), dim3(grid), dim3(64), 0, st, symbols, offsets, n, metric0, maxcycles,
                            ret, cycles, metric, maxnp, data, steps, scratch, counter);

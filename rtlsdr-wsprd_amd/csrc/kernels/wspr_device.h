@@ -13,8 +13,18 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace wspr {
+
+// Kernel-selection and measurement switches exist in the LAB build only (libwspr_mi355x_lab.so, -DWSPR_LAB: what the
+// parity suite and bench.py's kernel-level timings load); in the product library every one of them reads as unset, so
+// the product carries no way to pick a different kernel, repeat a stage or fold virtual devices.
+#ifdef WSPR_LAB
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
 
 constexpr int kMaxSamples = 45000;
 constexpr int kIqStride   = 45056;      // 176 * 256

@@ -12,8 +12,8 @@ import rtlsdr_wsprd_amd as w
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "wspr_mi355x.h")).read()
+def declared_symbols(header="wspr_mi355x.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     funcs = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src))
     funcs.discard("defined")
@@ -37,6 +37,38 @@ def test_library_exports_nothing_but_the_declared_symbols():
     out = subprocess.run(["nm", "-D", "--defined-only", w.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert exported == funcs | data, (sorted(exported - funcs - data), sorted((funcs | data) - exported))
+
+
+def test_lab_library_is_the_product_plus_the_bench_header():
+    """libwspr_mi355x_lab.so (the same sources with -DWSPR_LAB: what the parity suite uses for stage hooks, trace, kernel
+    timings and calibration) exports the drop-in header AND include/wspr_mi355x_bench.h, nothing else; none of the bench
+    header's functions is in the product."""
+    funcs, data = declared_symbols()
+    bfuncs, bdata = declared_symbols("wspr_mi355x_bench.h")
+    assert {"wspr_decode_batch_trace", "wspr_stage_fft_bank", "wspr_stage_candidates", "wspr_bench_fft_sync", "wspr_bench_valu",
+            "wspr_bench_decimate", "wspr_calib_read", "wspr_calib_copy", "wspr_calib_copy16", "wspr_calib_valu",
+            "wspr_set_front_end_cus"} == bfuncs and not bdata
+    out = subprocess.run(["nm", "-D", "--defined-only", w.LAB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == funcs | data | bfuncs
+    prod = subprocess.run(["nm", "-D", "--defined-only", w.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not ({ln.split()[-1] for ln in prod.splitlines() if ln.strip()} & bfuncs)
+
+
+def test_product_reads_five_environment_variables_and_no_kernel_switch():
+    """The laboratory is out of the product (verdict of round 4): the product library carries the names of its five
+    documented runtime knobs and of no kernel-selection / repeat / virtual-device switch; the lab library carries those."""
+    prod = open(w.LIB_PATH, "rb").read()
+    lab = open(w.LAB_PATH, "rb").read()
+    knobs = [b"WSPR_HOST_THREADS", b"WSPR_SLOTS", b"WSPR_BLOCKING_SYNC", b"WSPR_FANO_DEVICE", b"WSPR_FANO_FAST"]
+    switches = [b"WSPR_K0_KERNEL", b"WSPR_K0_RESIDENT", b"WSPR_K0_CUS", b"WSPR_K1_FUSED", b"WSPR_K3_KERNEL", b"WSPR_K4_LAG",
+                b"WSPR_K4_FREQ", b"WSPR_K4_DRIFT", b"WSPR_REPEAT_LAG", b"WSPR_REPEAT_FREQ", b"WSPR_REPEAT_FANO",
+                b"WSPR_FANO_WAVE_CAP", b"WSPR_NODE_VIRTUAL"]
+    assert all(k in prod for k in knobs)
+    assert not [k for k in switches if k in prod]
+    assert all(k in lab for k in switches)
+    names = set(re.findall(rb"WSPR_[A-Z0-9_]+", prod))
+    assert names <= set(knobs) | {b"WSPR_HASH_REVISIT"}, names
 
 
 def test_set_device_rejects_devices_that_do_not_exist():

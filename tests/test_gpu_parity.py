@@ -57,7 +57,7 @@ def test_fft_bank_bit_exact_vs_oracle_and_close_to_numpy(w, synth_batch, ref_iq)
     Q = np.stack([ref_iq[1], synth_batch[1][0], synth_batch[1][6]])
     blocks = 347
     out = np.zeros((3, 512, blocks), np.float32)
-    rc = w.lib().wspr_stage_fft_bank(ol.ptr(I), ol.ptr(Q), 3, NS, NS, ol.ptr(out))
+    rc = w.lab().wspr_stage_fft_bank(ol.ptr(I), ol.ptr(Q), 3, NS, NS, ol.ptr(out))
     assert rc == blocks
     for s in range(3):
         ps = oracle_ps(I[s], Q[s])
@@ -93,7 +93,7 @@ def test_candidates_match_oracle(w, synth_batch, ref_iq, coarse):
     npk = (C.c_int * nseg)()
     noise = np.zeros(nseg, np.float32)
     sm = np.zeros((nseg, 411), np.float32)
-    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, coarse, 4, C.addressof(cands),
+    rc = w.lab().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, coarse, 4, C.addressof(cands),
                                        C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
     assert rc == 0
     for s in range(nseg):
@@ -124,7 +124,7 @@ def test_equal_snr_ties_keep_the_reference_order(w):
     for coarse in (0, 1):
         cands = (w.cand * (200 * 2))()
         npk = (C.c_int * 2)()
-        assert w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), 2, NS, NS, coarse, 4, C.addressof(cands),
+        assert w.lab().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), 2, NS, NS, coarse, 4, C.addressof(cands),
                                              C.addressof(npk), None, None) == 0
         for s in range(2):
             onpk, oc, _, _ = _oracle_cands(I[s], Q[s], coarse)
@@ -156,7 +156,7 @@ def test_coarse_sync_of_a_large_batch_matches_oracle(w, synth_batch, ref_iq, max
     npk = (C.c_int * nseg)()
     noise = np.zeros(nseg, np.float32)
     sm = np.zeros((nseg, 411), np.float32)
-    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, 1, maxdrift, C.addressof(cands),
+    rc = w.lab().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, 1, maxdrift, C.addressof(cands),
                                        C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
     assert rc == 0
     L = ol.lib()
@@ -189,7 +189,7 @@ def test_short_records_through_the_fused_fft_bank(w, synth_batch, ref_iq, sample
     npk = (C.c_int * nseg)()
     noise = np.zeros(nseg, np.float32)
     sm = np.zeros((nseg, 411), np.float32)
-    rc = w.lib().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, samples, samples, 0, 4, C.addressof(cands),
+    rc = w.lab().wspr_stage_candidates(ol.ptr(I), ol.ptr(Q), nseg, samples, samples, 0, 4, C.addressof(cands),
                                        C.addressof(npk), ol.ptr(noise), ol.ptr(sm))
     assert rc == 0
     L = ol.lib()
@@ -765,7 +765,7 @@ def test_wave_fano_with_a_small_stack_in_a_subprocess():
     fills at those widths; a vector whose stack overflows all the same is finished by the host routine (exact)."""
     import subprocess
     import sys
-    env = dict(os.environ, WSPR_FANO_WAVE_CAP="1024")
+    env = dict(os.environ, WSPR_FANO_WAVE_CAP="1024", WSPR_USE_LAB="1")      # the switch exists in the lab build only
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_wave_fano_equals_host_fano"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -857,11 +857,11 @@ def test_hashtable_option_on_a_batch_decodes_in_order(w, tmp_path):
 
 
 # ------------------------------------------------------------------ node-level call
-def _node(w, I, Q, ndev, max_results=16):
+def _node(w, I, Q, ndev, max_results=16, lab=False):
     nseg = I.shape[0]
     out = (w.decoder_results * (nseg * max_results))()
     nres = (C.c_int * nseg)()
-    rc = w.lib().wspr_decode_batch_node(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, w.default_options(), C.addressof(out),
+    rc = (w.lab() if lab else w.lib()).wspr_decode_batch_node(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, w.default_options(), C.addressof(out),
                                         max_results, C.addressof(nres), ndev)
     return rc, [[_spot_tuple(out[s * max_results + i]) for i in range(nres[s])] for s in range(nseg)]
 
@@ -881,8 +881,14 @@ def test_node_level_call_equals_one_device_batch(w, synth_batch, monkeypatch):
     ndev = L.wspr_device_count()
     rc, got = _node(w, I, Q, ndev + 2)
     assert rc == -1 and all(len(g) == 0 for g in got)
+    # the test hook lives in the lab build only: the product refuses more shards than devices whatever the environment says
     monkeypatch.setenv("WSPR_NODE_VIRTUAL", "1")
     rc, got = _node(w, I, Q, 3 * ndev)
+    assert rc == -1
+    L = w.lab()
+    L.wspr_decode_batch_node.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rc, got = _node(w, I, Q, 3 * ndev, lab=True)
     assert rc == 0 and got == want
     lo, hi = C.c_int(), C.c_int()
     L.wspr_shard_range(8, 1, 3, C.byref(lo), C.byref(hi))

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtlsdr_wsprd_amd as w
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 nsig = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 sizes = [int(x) for x in sys.argv[2:]] or [128, 256, 512, 1024, 2048]
 if nsig == 1:

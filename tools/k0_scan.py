@@ -9,7 +9,7 @@ nseg = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 RAW = 576_000_000
 dev = torch.device("cuda", 0)
 raw = torch.randint(1, 256, (nseg, RAW), device=dev, dtype=torch.uint8)      # no 0x00: the dot-product path
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 stride = int(L.wspr_iq_stride())
 I = torch.zeros(nseg, stride, device=dev); Q = torch.zeros_like(I)
 ms = (C.c_double * 1)()

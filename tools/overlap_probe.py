@@ -9,7 +9,7 @@ import torch
 import rtlsdr_wsprd_amd as w
 import bench
 dev = torch.device("cuda", 0)
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 nraw, RAW = 32, 576_000_000
 raw = torch.randint(1, 256, (nraw, RAW), device=dev, dtype=torch.uint8)
 stride = int(L.wspr_iq_stride())

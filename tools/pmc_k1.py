@@ -13,7 +13,7 @@ nseg = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nsig = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 L.wspr_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 n = 1 << 28                                    # 1 GiB of floats: far beyond the 256 MiB Infinity Cache
 src = torch.rand(n, device=dev); dst = torch.empty_like(src)

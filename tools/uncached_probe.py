@@ -8,7 +8,7 @@ import torch
 import rtlsdr_wsprd_amd as w
 import bench
 dev = torch.device("cuda", 0)
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 hip = C.CDLL("libamdhip64.so")
 nraw, RAW = 32, 576_000_000
 src = torch.randint(1, 256, (nraw, RAW), device=dev, dtype=torch.uint8)

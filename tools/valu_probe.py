@@ -16,7 +16,7 @@ if nsig == 1:
 else:
     I, Q, _ = bench.synth_batch_gpu(nseg, 99, dev, nsig, -10.0, -28.0, 0.3)
 torch.cuda.synchronize()
-L = w.lib()
+L = w.lab()          # timing / calibration entry points: the lab library (include/wspr_mi355x_bench.h)
 L.wspr_bench_valu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
 ms = (C.c_double * 8)()
 L.wspr_bench_valu(I.data_ptr(), Q.data_ptr(), nseg, 45000, I.stride(0), iters, C.addressof(ms))
