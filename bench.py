@@ -46,10 +46,12 @@ STAGE_BYTES = K1_BYTES + K23_BYTES           # 1 517 592 B per segment per pass
 HBM_PEAK_GBS = 8000.0
 
 
-def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_jitter=1.0, chunk=256):
+def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_jitter=1.0, chunk=256, frac23=0.0):
     """Synthetic segments generated on the GPU (tests/synth.py is the numpy twin).
     n_signals = 1: SURVEY config 2 (f0 ~ U(-100,100) Hz, t0 = 2 s +- 1 s).
-    n_signals > 1: config 3 (frequency slots across +-100 Hz, SNR linearly snr_hi..snr_lo, t0 +- 0.3 s)."""
+    n_signals > 1: config 3 (frequency slots across +-100 Hz, SNR linearly snr_hi..snr_lo, t0 +- 0.3 s).
+    frac23 > 0: that share of the signals comes from compound-call stations alternating between their type-2 and
+    type-3 messages from segment to segment (-H traffic, synth.station_message)."""
     import synth
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -63,7 +65,11 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
     ar = torch.arange(162 * 256, device=dev)
     for c0 in range(0, nseg, chunk):
         n = min(chunk, nseg - c0)
-        msgs = [[synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(n_signals)] for _ in range(n)]
+        if frac23 > 0.0:
+            msgs = [[synth.station_message(int(rng.integers(0, 8)), c0 + r) if rng.random() < frac23
+                     else synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(n_signals)] for r in range(n)]
+        else:
+            msgs = [[synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(n_signals)] for _ in range(n)]
         for row in msgs:
             for m in row:
                 if m not in sym_cache:
@@ -341,7 +347,7 @@ def child_bench(args, config, steps, warmup, inflight=None, cpu_share=None, spaw
                                                              "OMP_NUM_THREADS")}
     cmd = [sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", str(steps), "--warmup", str(warmup),
            "--no-cpu-baseline", "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case",
-           "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-kernel-roofline"]
+           "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-hashtable-block", "--no-kernel-roofline"]
     if inflight:
         cmd += ["--inflight", str(inflight)]
     if cpu_share:
@@ -412,6 +418,144 @@ def shard_block(args, full_host):
     return blk
 
 
+def host_entry_block(dev, lanes, resident):
+    """The reference's OWN calling convention at speed: wspr_decode() takes host buffers (wsprd.h:106-111; call sites
+    rtlsdr_wsprd.c:316, :689), so does wspr_decode_batch().  configs[1] and configs[2] again with the IQ in CALLER HOST
+    MEMORY -- pageable (the library gathers the rows through its pinned chunk ring) and pinned with
+    wspr_pin_host_buffer() (plain DMA) -- twelve calls in flight on twelve lanes, next to the resident figure of the same
+    process and the box's host-to-device rate (what bounds configs[1]: 360 000 bytes per segment).  Never `value`."""
+    L = w.lib()
+    out = {"bytes_per_segment": 2 * 4 * NS}
+    # the link: one linear pinned -> device copy of 1 GiB, five times
+    src = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    out["h2d_GBs"] = 5 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+    out["pcie_bound_segments_per_s"] = out["h2d_GBs"] * 1e9 / (2 * 4 * NS)
+    del src, dst
+    torch.cuda.empty_cache()
+    opt = w.default_options()
+    inflight = len(lanes)
+    for ex in lanes:
+        ex.submit(L.wspr_set_thread_slots, 1).result()
+    for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 8192, 10, 12, 32)):
+        if nsig == 1:
+            I, Q, _ = synth_batch_gpu(nseg, 1234, dev, 1, -20.0, -20.0, 1.0)
+        else:
+            I, Q, _ = synth_batch_gpu(nseg, 4321, dev, 10, -10.0, -28.0, 0.3)
+        torch.cuda.synchronize()
+        Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
+        outs = [((w.decoder_results * (nseg * K))(), (C.c_int * nseg)()) for _ in range(inflight)]
+
+        def run(fn, n):
+            pend = []
+            for s in range(n):
+                if len(pend) >= inflight:
+                    pend.pop(0).result()
+                pend.append(lanes[s % inflight].submit(fn, s % inflight))
+            for f in pend:
+                f.result()
+
+        def timed(fn):
+            run(fn, inflight)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(fn, steps)
+            el = time.perf_counter() - t0
+            return {"value": nseg * steps / el, "unit": "segments/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+                    "iq_GBs": 2 * 4 * NS * nseg * steps / el / 1e9}
+
+        def resident_call(k):
+            o, n = outs[k]
+            assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), opt, C.addressof(o), K, C.addressof(n)) == 0
+
+        def host_call(k):
+            o, n = outs[k]
+            assert L.wspr_decode_batch(Ih.ctypes.data_as(C.c_void_p), Qh.ctypes.data_as(C.c_void_p), nseg, NS, NS, opt,
+                                       C.addressof(o), K, C.addressof(n), 0) == 0
+        blk = {"segments": nseg, "signals_per_segment": nsig, "batches_in_flight": inflight}
+        blk["resident"] = timed(resident_call)
+        want = list(outs[0][1])
+        del I, Q
+        torch.cuda.empty_cache()
+        blk["host_pageable"] = timed(host_call)
+        same = list(outs[0][1]) == want
+        assert L.wspr_pin_host_buffer(Ih.ctypes.data_as(C.c_void_p), Ih.nbytes) == 0
+        assert L.wspr_pin_host_buffer(Qh.ctypes.data_as(C.c_void_p), Qh.nbytes) == 0
+        blk["host_pinned"] = timed(host_call)
+        same = same and list(outs[0][1]) == want
+        L.wspr_unpin_host_buffer(Ih.ctypes.data_as(C.c_void_p))
+        L.wspr_unpin_host_buffer(Qh.ctypes.data_as(C.c_void_p))
+        blk["spot_counts_equal_resident"] = same
+        for kind in ("host_pageable", "host_pinned"):
+            blk[kind]["of_resident"] = blk[kind]["value"] / blk["resident"]["value"]
+            blk[kind]["of_pcie_bound"] = blk[kind]["value"] / out["pcie_bound_segments_per_s"]
+        out[name] = blk
+        del Ih, Qh, outs
+        L.wspr_release_buffers()
+    return out
+
+
+def hashtable_block(dev, lanes):
+    """usehashtable (-H, what real traffic needs: SURVEY 8 f3) on a BATCH.  Rounds 2-4 decoded such a batch one segment at
+    a time; since round 5 it is decoded in parallel against a logged view of the ordered hash memory and only the
+    segments whose look-ups would have seen something else are decoded again.  configs[2]-shaped
+    traffic, 5 % of the signals type 2 / type 3: the same batch without the option, with it from an EMPTY
+    hashtable.txt (every hashed call of the batch resolves through an earlier segment of the batch: the worst case) and
+    again with the file the first call wrote (a service's steady state).  One call at a time: calls with the option
+    take turns by definition (each reads the file the previous one wrote)."""
+    import shutil
+    import tempfile
+    L = w.lib()
+    nseg, K = 8192, 32
+    I, Q, _ = synth_batch_gpu(nseg, 2468, dev, 10, -10.0, -28.0, 0.3, frac23=0.05)
+    torch.cuda.synchronize()
+    out = (w.decoder_results * (nseg * K))()
+    nres = (C.c_int * nseg)()
+    lane = lanes[0]
+    lane.submit(L.wspr_set_thread_slots, 0).result()            # a lone call: the library's own three pipelines
+
+    def call(use):
+        o = w.default_options()
+        o.usehashtable = use
+        t0 = time.perf_counter()
+        assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), o, C.addressof(out), K, C.addressof(nres)) == 0
+        return time.perf_counter() - t0
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp(prefix="wspr_hash_", dir="/tmp")
+    try:
+        os.chdir(tmp)
+        for _ in range(3):
+            lane.submit(call, 0).result()
+        plain = min(lane.submit(call, 0).result() for _ in range(3))
+        n_plain = int(sum(nres))
+        unresolved_plain = sum(1 for s in range(nseg) for i in range(nres[s]) if out[s * K + i].message.startswith(b"<...>"))
+        cold = lane.submit(call, 1).result()
+        n_cold = int(sum(nres))
+        warm = min(lane.submit(call, 1).result() for _ in range(3))
+        unresolved_warm = sum(1 for s in range(nseg) for i in range(nres[s]) if out[s * K + i].message.startswith(b"<...>"))
+        entries = sum(1 for _ in open("hashtable.txt"))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    del I, Q
+    L.wspr_release_buffers()
+    return {"workload": "configs[2]-shaped: %d segments x 10 signals, 5 %% of them type 2 / type 3 (compound-call stations "
+                        "alternating between both), one call at a time, three pipelines per call" % nseg,
+            "without_option": {"value": nseg / plain, "unit": "segments/s", "ms_per_call": 1e3 * plain, "spots": n_plain,
+                               "unresolved_hashed_calls": unresolved_plain},
+            "with_option_empty_file": {"value": nseg / cold, "unit": "segments/s", "ms_per_call": 1e3 * cold, "spots": n_cold,
+                                       "of_without_option": plain / cold},
+            "with_option_file_of_the_previous_call": {"value": nseg / warm, "unit": "segments/s", "ms_per_call": 1e3 * warm,
+                                                      "of_without_option": plain / warm,
+                                                      "unresolved_hashed_calls": unresolved_warm},
+            "hashtable_entries": entries}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: re-executes this script as N ranks of ONE node under
     torch.distributed.run (one rank per GPU, RCCL over xGMI, rendezvous on 127.0.0.1), each rank with its share of
@@ -467,6 +611,7 @@ def main():
                     help="skip the configs3_shard block (the per-rank shard of configs[3]: full host, 1/8 of the CPUs, world-1 RCCL)")
     ap.add_argument("--no-host-entry", action="store_true",
                     help="skip the host_entry block (the reference's own calling convention: host buffers in, wsprd.h:106-111)")
+    ap.add_argument("--no-hashtable-block", action="store_true", help="skip the usehashtable_batch block (-H on a batch)")
     ap.add_argument("--no-kernel-roofline", action="store_true",
                     help="child runs: skip the kernel-level timing sets behind the roofline block (the line then carries no roofline)")
     ap.add_argument("--no-pmc", action="store_true",
@@ -879,6 +1024,17 @@ def main():
             torch.cuda.empty_cache()
             L.wspr_release_buffers()
             shard = shard_block(args, full)
+        host_entry = None
+        if world == 1 and args.config == 3 and not args.no_host_entry and not use_dist:
+            I = Q = None
+            m["I"] = m["Q"] = None
+            torch.cuda.empty_cache()
+            L.wspr_release_buffers()
+            host_entry = host_entry_block(dev, lanes[:12], m["value"])
+        hashtable = None
+        if world == 1 and args.config == 3 and not args.no_hashtable_block and not use_dist:
+            torch.cuda.empty_cache()
+            hashtable = hashtable_block(dev, lanes)
         out = {
             "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
             "unit": "segments/s", "n_gpus": world, "distinct_devices": distinct_devices,
@@ -902,7 +1058,8 @@ def main():
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
             "host_pool_workers": int(L.wspr_host_pool_workers()),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,
-            "configs3_shard": shard, "fanout_check": fanout,
+            "configs3_shard": shard, "host_entry": host_entry, "usehashtable_batch": hashtable,
+            "fanout_check": fanout,
         }
         if world == 1 and not use_dist and args.config == 3:
             if not args.no_reference_case:

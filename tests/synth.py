@@ -13,6 +13,16 @@ GRIDS = ["FN20", "FN31", "FN35", "IO91", "PM95", "EN50", "JO62", "QF56", "KG33",
          "KP20", "GG66", "GF05", "IN80", "JN45", "JO89", "KO85", "PL05", "PM37", "RE78"]
 POWERS = [0, 3, 7, 10, 13, 17, 20, 23, 27, 30, 33, 37, 40, 43, 47, 50, 53, 57, 60]
 NS = 45000
+# compound calls (type 2) and the 6-character locators their stations send in the hashed form (type 3), for -H traffic
+STATIONS = [("PJ4/K1ABC", "FK52UD", 37), ("K1ABC/7", "DN40AB", 30), ("VP9/W1AW", "FM72PH", 23), ("G4ABC/P", "IO91WM", 27),
+            ("F/DL0ABC", "JN18DU", 33), ("ZS6BKW/5", "KG33XX", 20), ("EA8/OH2AB", "IL18QI", 40), ("JA1XYZ/1", "PM95RR", 10)]
+
+
+def station_message(st, seg):
+    """Station st's transmission in segment seg: stations alternate between their type-2 and type-3 messages from slot to
+    slot, as real ones do."""
+    call, grid6, pwr = STATIONS[st % len(STATIONS)]
+    return ("%s %d" % (call, pwr)) if (seg + st) % 2 == 0 else ("<%s> %s %d" % (call, grid6, pwr))
 
 
 def message_for(idx):
@@ -21,7 +31,10 @@ def message_for(idx):
 
 
 def expected_text(msg):
-    """Decoder prints a type-1 power with two digits (wsprd_utils.c:259)."""
+    """Decoder prints a type-1 power with two digits (wsprd_utils.c:259); type-2 / type-3 texts come back as sent (the
+    hashed call resolved)."""
+    if "/" in msg or msg.startswith("<"):
+        return msg
     c, g, p = msg.split()
     return "%s %s %02d" % (c, g, int(p))
 

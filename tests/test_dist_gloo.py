@@ -338,7 +338,9 @@ def test_world2_hashtable_without_turns_through_the_product(tmp_path):
     finally:
         os.chdir(cwd)
     assert got == ref and open(shared / "hashtable.txt").read() == ref_file
-    assert got[3] == ["<PJ4/K1ABC> FK52UD 37"] and rounds[0] >= 2
+    # (rank 1 revisits once it has seen rank 0's stores; its own stores do not change -- a type-3 decode stores nothing --
+    # so the exchange may already be over after the first round)
+    assert got[3] == ["<PJ4/K1ABC> FK52UD 37"] and all(1 <= r <= 3 for r in rounds)
 
 
 # ---- real-input fan-out: rank 0 holds the IQ, the other ranks receive their rows -----------------

@@ -18,9 +18,7 @@ import synth
 pytestmark = pytest.mark.gpu
 NS = 45000
 
-# compound calls (type 2) and the 6-character locators their stations send in the hashed form (type 3)
-STATIONS = [("PJ4/K1ABC", "FK52UD", 37), ("K1ABC/7", "DN40AB", 30), ("VP9/W1AW", "FM72PH", 23), ("G4ABC/P", "IO91WM", 27),
-            ("F/DL0ABC", "JN18DU", 33), ("ZS6BKW/5", "KG33XX", 20), ("EA8/OH2AB", "IL18QI", 40), ("JA1XYZ/1", "PM95RR", 10)]
+STATIONS = synth.STATIONS
 
 
 @pytest.fixture(scope="module")
@@ -49,9 +47,7 @@ def _traffic(nseg, frac23, seed, nsig=3, snr=-9.0):
         msgs = []
         for k in range(nsig):
             if rng.random() < frac23:
-                st = int(rng.integers(0, len(STATIONS)))
-                call, grid6, pwr = STATIONS[st]
-                m = ("%s %d" % (call, pwr)) if (s + st) % 2 == 0 else ("<%s> %s %d" % (call, grid6, pwr))
+                m = synth.station_message(int(rng.integers(0, len(STATIONS))), s)
             else:
                 m = synth.message_for(int(rng.integers(0, 1 << 20)))
             msgs.append(m)

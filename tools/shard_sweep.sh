@@ -2,7 +2,7 @@
 # configs[3]'s per-rank shard (bench.py --config 4) by batches in flight and CPU share; one JSON line per run
 out=${1:-gpurun_out/shard_sweep.jsonl}
 : > "$out"
-slim="--no-cpu-baseline --no-secondary --no-tertiary --no-pmc --no-share-block --no-reference-case --no-ceilings --no-shard-block --no-host-entry --no-kernel-roofline"
+slim="--no-cpu-baseline --no-secondary --no-tertiary --no-pmc --no-share-block --no-reference-case --no-ceilings --no-shard-block --no-host-entry --no-hashtable-block --no-kernel-roofline"
 for share in 0 2; do
   for inf in 1 2 4 8 12; do
     extra=""; [ "$share" != 0 ] && extra="--cpu-share $share"
