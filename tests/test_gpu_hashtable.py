@@ -148,7 +148,8 @@ def test_batch_with_hashtable_equals_the_serial_walk(w, tmp_path, frac23, nseg):
             return _hashed(w, I, Q)
         (sp2, _, n_re2, _, _), _ = _in_dir(tmp_path / "twice", twice)
         assert n_re2 == 0
-        assert sum(m.startswith(b"<...>") for seg in sp2 for (m, *_) in seg) == 0
+        # (a station heard only in its hashed form stays "<...>": never more of those than in the first pass)
+        assert sum(m.startswith(b"<...>") for seg in sp2 for (m, *_) in seg) <= unresolved
 
 
 def test_sharded_hashed_calls_equal_one_batch(w, tmp_path):
