@@ -214,6 +214,8 @@ struct SegBook {                 // host bookkeeping of one segment across passe
 
 struct Context::Impl {
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr; // host-buffer loads, at the highest stream priority (see load_host)
+    hipEvent_t ev_copy = nullptr;
     hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
     int fe_cus = 0;                    // CUs the mask of fe_stream admits (0: fe_stream not in use)
     int device = 0;
@@ -322,6 +324,12 @@ Context::Context(int nslots) : d(new Impl) {
     HIP_OK(hipEventCreateWithFlags(&d->ev_sync, evflags | hipEventDisableTiming));
     for (auto& pr : d->ev_def) { HIP_OK(hipEventCreate(&pr[0])); HIP_OK(hipEventCreate(&pr[1])); }
     for (auto& e : d->ev_stage) HIP_OK(hipEventCreateWithFlags(&e, evflags | hipEventDisableTiming));
+    {
+        int least = 0, greatest = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_OK(hipStreamCreateWithPriority(&d->copy_stream, hipStreamNonBlocking, greatest));
+        HIP_OK(hipEventCreateWithFlags(&d->ev_copy, hipEventDisableTiming));
+    }
 
     // constant tables, computed with the host libm exactly as the reference does
     std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
@@ -498,42 +506,68 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
     float* wi = work_i(nseg);
     float* wq = work_q(nseg);
     if (nseg <= 0) return;
-    std::lock_guard<std::mutex> turn(host_load_turn(c.device));
+    // The transfers run on a stream of the HIGHEST priority and the decode stream waits for its last event.  Measured
+    // (tools/dma_interference.py): beside twelve lanes of decoder kernels a linear pinned-to-device copy on an ordinary
+    // stream gets 10-18 GB/s of the link's 55 -- its queue's packets wait their turn behind kernels -- and 35 GB/s on a
+    // high-priority stream, with the decoder's step unchanged either way (the DMA engines do the work).
+    const hipStream_t ld = c.copy_stream;
+    struct Join {                                                    // whatever path is taken: the decode stream follows the load
+        Impl& c;
+        ~Join() {
+            (void)hipEventRecord(c.ev_copy, c.copy_stream);
+            (void)hipStreamWaitEvent(c.stream, c.ev_copy, 0);
+        }
+    } join{c};
+    // One load at a time per device (the turnstile): the lane whose turn it is has the link to itself and its batch in
+    // HBM after 1/n of the time n concurrent loads would take -- and starts computing under the next lane's transfer.
+    std::unique_lock<std::mutex> turn(host_load_turn(c.device), std::defer_lock);
+    auto finish_turn = [&] {                                     // the turn ends when the LINK is free again, not when
+        HIP_OK(hipEventRecord(c.ev_copy, ld));                   // the copies have merely been queued
+        host_wait(c.ev_copy);
+    };
     if (host_is_pinned(I) && host_is_pinned(Q)) {
+        turn.lock();
         // Pinned rows: LINEAR copies (the DMA engines at the link's rate, no CU involved) of up to kDense rows at a time
         // into a dense device buffer, and the row kernel that also serves resident input spreads them into the working
         // layout (device to device, microseconds).  A strided host-to-device copy straight into the working rows measured
-        // 40-45 GB/s against 55 for the linear one and cost the decoder kernels of the other lanes 10-15 % (round 5).
+        // 40-45 GB/s against 55 for the linear one (round 5).
         if ((samples & 3) == 0 && (stride & 3) == 0 && !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
-            constexpr int kDense = 512;
+            constexpr int kDense = 256;
             const int per = std::min(nseg, kDense);
-            float* dn = static_cast<float*>(c.densein.need((size_t)2 * per * stride * 4));
-            for (int c0 = 0; c0 < nseg; c0 += per) {
+            // two dense buffers in turn: the row kernel of chunk k runs under the DMA of chunk k + 1
+            float* dn0 = static_cast<float*>(c.densein.need((size_t)4 * per * stride * 4));
+            for (int c0 = 0, k = 0; c0 < nseg; c0 += per, ++k) {
                 const int n = std::min(per, nseg - c0);
+                float* dn = dn0 + (size_t)(k & 1) * 2 * per * stride;
                 const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
-                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, c.stream));
-                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, c.stream));
+                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
+                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
                 if (!launch_load_rows(dn, dn + (size_t)per * stride, stride, samples, n, wi + (size_t)c0 * kIqStride,
-                                      wq + (size_t)c0 * kIqStride, c.stream))
+                                      wq + (size_t)c0 * kIqStride, ld))
                     throw std::runtime_error("load_rows refused an aligned dense chunk");
             }
-            return;
+        } else {
+            zero_tail(wi, wq, nseg, samples, ld);
+            HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
+            HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
         }
-        zero_tail(wi, wq, nseg, samples, c.stream);
-        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
-        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        if (nseg >= 16) finish_turn();
         return;
     }
     if (nseg < 16) {                                             // a single call's record or a handful: the runtime's own path
-        zero_tail(wi, wq, nseg, samples, c.stream);
-        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
-        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, c.stream));
+        zero_tail(wi, wq, nseg, samples, ld);
+        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
+        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
         return;
     }
-    constexpr int chunk = 96;                                    // segments per chunk: 17.3 MB per rail, two rails, two chunks
+    // Pageable rows: gathered by the host pool into this context's two pinned chunks, already in the working layout
+    // (rows of kIqStride floats, zero tail), each chunk then ONE linear copy per rail.  The first two chunks are gathered
+    // BEFORE the turn is taken (the link belongs to another lane meanwhile), the others under the DMA of their
+    // predecessors.
+    constexpr int chunk = 64;                                    // segments per chunk: 11.5 MB per rail, two rails, two chunks
     const size_t row = (size_t)kIqStride, rail = (size_t)chunk * row;      // floats; the layout of a chunk never changes
-    for (int c0 = 0, k = 0; c0 < nseg; c0 += chunk, ++k) {
-        const int n = std::min(chunk, nseg - c0), b = k & 1;
+    auto gather = [&](int k) {
+        const int c0 = k * chunk, n = std::min(chunk, nseg - c0), b = k & 1;
         const bool fresh = c.h_stage[b].cap < 2 * rail * 4;
         float* st = static_cast<float*>(c.h_stage[b].need(2 * rail * 4));
         if (fresh) { memset(st, 0, 2 * rail * 4); c.stage_samples[b] = 0; }
@@ -553,11 +587,23 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
         else for (int r = 0; r < n; ++r) fill(r);
         // every row of the chunk now ends at `samples` (rows beyond n: whatever they held, never sent)
         c.stage_samples[b] = (n == chunk) ? samples : std::max(dirty, samples);
-        HIP_OK(hipMemcpyAsync(wi + (size_t)c0 * row, st, (size_t)n * row * 4, hipMemcpyHostToDevice, c.stream));
-        HIP_OK(hipMemcpyAsync(wq + (size_t)c0 * row, st + rail, (size_t)n * row * 4, hipMemcpyHostToDevice, c.stream));
-        HIP_OK(hipEventRecord(c.ev_stage[b], c.stream));
-    }
-    // the chunks are read asynchronously; the caller's rows were consumed by the gather and may change from here on
+    };
+    auto send = [&](int k) {
+        const int c0 = k * chunk, n = std::min(chunk, nseg - c0), b = k & 1;
+        const float* st = c.h_stage[b].as<float>();
+        HIP_OK(hipMemcpyAsync(wi + (size_t)c0 * row, st, (size_t)n * row * 4, hipMemcpyHostToDevice, ld));
+        HIP_OK(hipMemcpyAsync(wq + (size_t)c0 * row, st + rail, (size_t)n * row * 4, hipMemcpyHostToDevice, ld));
+        HIP_OK(hipEventRecord(c.ev_stage[b], ld));
+    };
+    const int nchunks = (nseg + chunk - 1) / chunk;
+    gather(0);
+    if (nchunks > 1) gather(1);
+    turn.lock();
+    send(0);
+    if (nchunks > 1) send(1);
+    for (int k = 2; k < nchunks; ++k) { gather(k); send(k); }
+    finish_turn();
+    // the caller's rows were consumed by the gathers and may change from here on
 }
 void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {
     float* wi = work_i(nseg);

@@ -881,99 +881,17 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
         pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
 }
 
-// Round 5: the same sums with NO LDS and NO barrier.  Counters of round 4 said the twelve-wave kernel above waits
-// (VALU active 11 % of its wave cycles, 69 % waiting): sixteen barrier pairs couple twelve waves, with 32 samples of
-// work per lane between them, and every chunk goes global -> registers -> LDS -> registers.  Here a WAVE is on its own:
-// lane = symbol (three single-wave workgroups per candidate), a lane keeps the 16 samples of its symbol's current
-// chunk in registers (each lane reads whole 64-byte pieces of its own row: four 16-byte loads per rail and chunk,
-// nothing fetched twice) with the next chunk's loads in flight, and walks the FOUR hypotheses over those registers one
-// after the other -- a sample is fetched once for 64 packed multiply/adds instead of once per hypothesis.  A
-// hypothesis' table is wave-uniform and comes through the scalar cache (32 bytes per step), as before.  Per symbol
-// and hypothesis the operations and their order are those of freq_scalar_kernel (chunks in order, samples in order,
-// out-of-range samples as zeros): bit-identical outputs.
-constexpr int kFlChunk = 16;
-struct FlSamples { float4 i[kFlChunk / 4], q[kFlChunk / 4]; };
-
-__device__ __forceinline__ FlSamples fl_fetch(const float* __restrict__ xi, const float* __restrict__ xq, int k, int np,
-                                              bool working) {
-    FlSamples r;
-    if (working && k > 0 && k + kFlChunk <= np) {                       // every sample in (0, np): whole vectors
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows start anywhere: dword alignment only
-        const f4u* pi = reinterpret_cast<const f4u*>(xi + k);
-        const f4u* pq = reinterpret_cast<const f4u*>(xq + k);
-#pragma unroll
-        for (int v = 0; v < kFlChunk / 4; ++v) {
-            const f4u a = pi[v], b = pq[v];
-            r.i[v] = make_float4(a.x, a.y, a.z, a.w);
-            r.q[v] = make_float4(b.x, b.y, b.z, b.w);
-        }
-    } else {
-        float a[kFlChunk], b[kFlChunk];
-#pragma unroll
-        for (int e = 0; e < kFlChunk; ++e) {
-            const bool ok = working && (k + e > 0) && (k + e < np);
-            a[e] = ok ? xi[k + e] : 0.0f;
-            b[e] = ok ? xq[k + e] : 0.0f;
-        }
-#pragma unroll
-        for (int v = 0; v < kFlChunk / 4; ++v) {
-            r.i[v] = make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
-            r.q[v] = make_float4(b[4 * v], b[4 * v + 1], b[4 * v + 2], b[4 * v + 3]);
-        }
-    }
-    return r;
-}
-
-__global__ __launch_bounds__(64)
-void freq_lanesym_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                         const FineState* __restrict__ items, const int* __restrict__ item_list, int nitems,
-                         const float* __restrict__ tabs, float4* __restrict__ pw_out,
-                         const float4* __restrict__ pw_lag, int nlag, int lagstep) {
-    // 1-D grid, XCD-aware like the lag scan's: workgroup w serves candidate 8 * floor(w / 24) + w mod 8, wave
-    // (w / 8) mod 3 of it, so a candidate's three waves (one set of tables) sit behind one XCD's L2
-    const int w = blockIdx.x;
-    const int slot = 8 * (w / 24) + (w & 7);
-    if (slot >= nitems) return;
-    const int wv = (w >> 3) % 3;
-    const int item = item_list[slot];
-    const FineState st = items[item];
-    const int sym = wv * 64 + (int)threadIdx.x;
-    const bool working = sym < kNSymD;
-    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
-    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int k0 = st.shift + kSps * (working ? sym : 0);
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + (size_t)slot * kNFreq * (2 * kSps);
-
-    ToneAcc acc[kNFreq - 1];
-#pragma unroll
-    for (int h = 0; h < kNFreq - 1; ++h) acc[h].clear();
-    FlSamples nxt = fl_fetch(xi, xq, k0, np, working);
-    for (int c = 0; c < kSps / kFlChunk; ++c) {
-        const FlSamples cur = nxt;
-        if (c + 1 < kSps / kFlChunk) nxt = fl_fetch(xi, xq, k0 + kFlChunk * (c + 1), np, working);
-#pragma unroll
-        for (int h = 0; h < kNFreq - 1; ++h) {
-            const int f = h < kNFreq / 2 ? h : h + 1;
-            const float4* __restrict__ t = gt + (size_t)f * (2 * kSps) + 2 * kFlChunk * c;
-#pragma unroll
-            for (int v = 0; v < kFlChunk / 4; ++v) {
-                acc[h].step(make_float2(cur.i[v].x, cur.q[v].x), t[8 * v + 0], t[8 * v + 1]);
-                acc[h].step(make_float2(cur.i[v].y, cur.q[v].y), t[8 * v + 2], t[8 * v + 3]);
-                acc[h].step(make_float2(cur.i[v].z, cur.q[v].z), t[8 * v + 4], t[8 * v + 5]);
-                acc[h].step(make_float2(cur.i[v].w, cur.q[v].w), t[8 * v + 6], t[8 * v + 7]);
-            }
-        }
-    }
-    if (!working) return;
-#pragma unroll
-    for (int h = 0; h < kNFreq - 1; ++h) {
-        const int f = h < kNFreq / 2 ? h : h + 1;
-        pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc[h].amplitudes();
-    }
-    const int m_centre = centre_from_lag_scan(st, nlag, lagstep);
-    if (m_centre >= 0)
-        pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
-}
+// Round 5 tried these sums with NO LDS and NO barrier (verdict of round 4: VALU active 11 % of the wave cycles, 69 %
+// waiting): a wave on its own, lane = symbol, the lane's 8 or 16 samples of a chunk in registers with the next chunk's
+// loads in flight, the four hypotheses walked one after the other over those registers, tables through the scalar
+// cache a two- or four-step stage ahead; as three single-wave workgroups per candidate (XCD-aware) and as one workgroup
+// of three waves.  Bit-identical outputs (trace parity), 9 % fewer vector instructions -- and SLOWER: 0.51-0.58 ms per
+// 2 048 candidates against 0.43-0.44 for the kernel above on the same boxes, with the same counter picture (VALU active
+// 0.12-0.14, waiting 0.70-0.72: profiles/r05_freq_scan_barrier_free_ab.txt).  What the waves wait for is therefore not
+// the barriers but the TABLE: 32 KB per candidate streamed once through a 16 KB scalar cache, every 64-byte line a trip
+// to L2, and scalar loads return out of order, so a wave can be one stage ahead and no more (s_waitcnt lgkmcnt(0));
+// the twelve-wave form hides that latency better (24 waves per CU, three waves share each line).  The kernel was
+// deleted again; the experiment is in the history (commit "Barrier-free frequency scan kernel").
 
 // The centre hypothesis of the candidates freq_scalar_kernel could not copy it for (rare: no lag won; or nlag = 0,
 // the WSPR_K4_FREQ=nocentre switch of the trace tests): one wave per candidate checks, and sums the 162 symbols
@@ -1220,15 +1138,9 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     const int nlag_c = (pl && !nocentre) ? nlag_lag : 0;
     if (n_shared > 0) {
         hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-        // WSPR_K4_FREQ=twelve (lab build): round 4's twelve-wave kernel with its LDS tile instead of the barrier-free one
-        static const bool twelve = [] { const char* e = lab_env("WSPR_K4_FREQ"); return e && e[0] == 't'; }();
         for (int r = 0; r < rep_freq; ++r)
-            if (twelve)
-                hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
-                                   list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
-            else
-                hipLaunchKernelGGL(freq_lanesym_kernel, dim3(24 * ((n_shared + 7) / 8)), dim3(64), 0, st, dI, dQ, samples,
-                                   items, list_shared, n_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
+            hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
+                               list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
         hipLaunchKernelGGL(freq_centre_rare_kernel, dim3(n_shared), dim3(64), 0, st, dI, dQ, samples, items, list_shared,
                            tabs, reinterpret_cast<float4*>(pw), nlag_c, lagstep);
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,

@@ -88,6 +88,36 @@ def bg_copy(piece, pace_gbs=None, d2h=False):
     return f
 
 
+def bg_multi(nstreams, priority=0):
+    """nstreams copy streams at once, each moving its own quarter of the buffers in 64 MiB pieces"""
+    def f(stop, moved):
+        torch.cuda.set_device(0)
+        streams = [torch.cuda.Stream(priority=priority) for _ in range(nstreams)]
+        part = (1 << 30) // nstreams
+        piece = 1 << 26
+        while not stop.is_set():
+            evs = []
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    for off in range(k * part, (k + 1) * part, piece):
+                        dst[off:off + piece].copy_(src[off:off + piece], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(st); evs.append(ev)
+            for ev in evs:
+                while not ev.query():
+                    time.sleep(0.0005)
+            moved[0] += 1 << 30
+    return f
+
+
+mode = sys.argv[2] if len(sys.argv) > 2 else "all"
+if mode == "streams":
+    timed("resident alone")
+    timed("+ H2D, 1 stream, 64 MiB pieces", bg_multi(1))
+    timed("+ H2D, 4 streams", bg_multi(4))
+    timed("+ H2D, 8 streams", bg_multi(8))
+    timed("+ H2D, 1 high-priority stream", bg_multi(1, -1))
+    timed("+ H2D, 4 high-priority streams", bg_multi(4, -1))
+    sys.exit(0)
 timed("resident alone")
 timed("+ H2D 1 GiB copies, back to back", bg_copy(1 << 30))
 timed("+ H2D 16 MiB pieces, back to back", bg_copy(1 << 24))
