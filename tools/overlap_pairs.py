@@ -54,13 +54,54 @@ def alone(fn, iters, lane):
     return o["t"] / iters
 
 
+# shader clock and socket power, sampled three times a second and tagged with what is running: is the chip at its power
+# limit, so that two kernels together get a lower clock each -- i.e. ENERGY, not a pipe, is what they share?
+import re
+import subprocess
+phase = ["idle"]
+samples = {}
+stop_sampling = threading.Event()
+
+
+def sampler():
+    while not stop_sampling.is_set():
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            sclk = re.search(r"sclk clock level[^(]*\((\d+)Mhz\)", out)
+            pw = re.search(r"Package Power[^:]*:\s*([0-9.]+)", out)
+            if sclk and pw:
+                samples.setdefault(phase[0], []).append((int(sclk.group(1)), float(pw.group(1))))
+        except Exception:
+            pass
+        time.sleep(0.3)
+
+
+threading.Thread(target=sampler, daemon=True).start()
+
+
+def report(name):
+    v = samples.get(name, [])
+    if len(v) > 2:
+        v = v[1:]                                           # the first sample straddles the phase's start
+    if v:
+        print("    %-28s sclk %4.0f MHz (min %d), socket power %4.0f W over %d samples" %
+              (name, sum(a for a, _ in v) / len(v), min(a for a, _ in v), sum(b for _, b in v) / len(v), len(v)))
+
+
 for fn, n, lane in ((k0, 5, 0), (read, 5, 0), (valu, 3, 1), (regs, 5, 1)):
     alone(fn, n, lane)
+for name, fn, n, lane in (("K0 alone", k0, 700, 0), ("read alone", read, 800, 0), ("decoder set alone", valu, 400, 1),
+                          ("register VALU alone", regs, 550, 1)):
+    phase[0] = name
+    alone(fn, n, lane)
+    phase[0] = "idle"
+    report(name)
 t = {"K0": alone(k0, 40, 0), "read": alone(read, 40, 0), "decoder set": alone(valu, 20, 1), "register VALU": alone(regs, 40, 1)}
 print("alone, ms per launch (set): " + ", ".join("%s %.3f" % kv for kv in t.items()))
 fns = {"K0": k0, "read": read, "decoder set": valu, "register VALU": regs}
 for a, b in (("K0", "decoder set"), ("read", "decoder set"), ("K0", "register VALU"), ("read", "register VALU")):
-    target = 150.0                                           # ms of work each, alone
+    target = 2000.0                                          # ms of work each, alone (long enough for the power samples)
+    phase[0] = "%s || %s" % (a, b)
     na, nb = max(4, int(round(target / t[a]))), max(4, int(round(target / t[b])))
     o = {}
     t0 = time.perf_counter()
@@ -70,3 +111,6 @@ for a, b in (("K0", "decoder set"), ("read", "decoder set"), ("K0", "register VA
     wa, wb = na * t[a], nb * t[b]
     print("%-6s || %-14s: together %.1f ms; alone %.1f + %.1f = %.1f back to back, %.1f if they overlapped perfectly -> %.2f of the sum"
           % (a, b, wall, wa, wb, wa + wb, max(wa, wb), wall / (wa + wb)))
+    name = phase[0]
+    phase[0] = "idle"
+    report(name)

@@ -37,7 +37,7 @@ else
   mode="${3:-host}"; nseg="${4:-384}"
   export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=0:protect_shadow_gap=0" UBSAN_OPTIONS="print_stacktrace=1"
   export TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1:report_signal_unsafe=0"
-  log="${5:-/tmp/wspr_sanitize_${kind}_${mode}.log}"
+  log="$(realpath -m "${5:-/tmp/wspr_sanitize_${kind}_${mode}.log}")"
   cd "$out" && LD_LIBRARY_PATH="$out:$rt:/opt/rocm/lib:${LD_LIBRARY_PATH:-}" ./driver "$mode" "$nseg" > "$log" 2>&1 || true
   python3 "$root/tools/sanitize_summary.py" "$log"
 fi
