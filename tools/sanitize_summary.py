@@ -1,34 +1,52 @@
 #!/usr/bin/env python3
-"""Summary of a sanitizer log (tools/sanitize.sh run ...): reports by SUMMARY line, and -- what matters -- the reports
-with a frame of THIS library's own code in either stack (libwspr_mi355x_lab.so / wspr:: / sanitize_driver), apart from
-the HIP module constructor / destructor the runtime registers for every shared object."""
+"""Summary of a sanitizer log (tools/sanitize.sh run ...).  A report has one stack per access; the frame that matters is
+the first one below the sanitizer's own interceptors: the code that performed the racing (or invalid) access.  Reports
+are counted by the module of that frame -- the library / the driver ("ours") or the uninstrumented HIP / HSA runtime,
+whose internal accesses ThreadSanitizer only sees through intercepted libc calls (memcpy, free, pthread_*), with this
+library merely further up the stack as the caller of a HIP API."""
 import re
 import sys
 
 txt = open(sys.argv[1], errors="replace").read()
-reports = re.split(r"={18}\n", txt)
-reports = [r for r in reports if "WARNING:" in r or "ERROR:" in r]
-by_summary, ours = {}, []
+reports = [r for r in re.split(r"={18}\n", txt) if "WARNING:" in r or "ERROR:" in r]
+
+
+def owner(frame):
+    if "libwspr_mi355x" in frame or "sanitize_driver" in frame or "(driver+" in frame:
+        return "ours"
+    m = re.search(r"\(([^()\s]+?\.so[0-9.]*)\+0x", frame)
+    return m.group(1) if m else "other"
+
+
+by_kind, ours = {}, []
 for r in reports:
-    m = re.search(r"SUMMARY: (\w+Sanitizer: [^\n(]*)\(([^)+]*)", r)
-    key = (m.group(1).strip() + " in " + m.group(2).split("/")[-1]) if m else "no summary"
-    by_summary[key] = by_summary.get(key, 0) + 1
-    frames = [ln for ln in r.splitlines() if re.match(r"\s+#\d+", ln)]
-    mine = [f for f in frames if ("libwspr_mi355x" in f or "wspr::" in f or "sanitize_driver" in f)
-            and "__hip_module_ctor" not in f and "__hip_module_dtor" not in f]
-    if mine:
-        ours.append((key, mine[:4]))
-print("%d reports" % len(reports))
-for k, v in sorted(by_summary.items(), key=lambda kv: -kv[1]):
-    print("  %4d  %s" % (v, k))
-print("%d of them with a frame of the library's or the driver's own code (module constructors excluded):" % len(ours))
-seen = {}
-for k, fr in ours:
-    sig = (k, tuple(re.sub(r"0x[0-9a-f]+", "", f).strip() for f in fr[:2]))
-    seen[sig] = seen.get(sig, 0) + 1
-for (k, fr), n in sorted(seen.items(), key=lambda kv: -kv[1]):
-    print("  %3d x %s" % (n, k))
+    kind = re.search(r"(?:WARNING|ERROR): (\w+Sanitizer: [^\n(]*)", r)
+    kind = kind.group(1).strip() if kind else "?"
+    stacks, cur = [], None
+    for ln in r.splitlines():
+        if re.match(r"\s+#\d+ ", ln):
+            if cur is not None:
+                cur.append(ln.strip())
+        elif ln.startswith("  ") and ln.rstrip().endswith(":") and ("thread" in ln or "of size" in ln or "by" in ln):
+            cur = []
+            stacks.append((ln.strip(), cur))
+    access = [s for s in stacks if re.search(r"of size|Atomic|[Rr]ead|[Ww]rite|free", s[0])][:2]
+    owners = []
+    for title, fr in access:
+        first = next((f for f in fr if "libclang_rt" not in f), fr[0] if fr else "")
+        owners.append(owner(first))
+    key = (kind, tuple(sorted(set(owners))) or ("?",))
+    by_kind[key] = by_kind.get(key, 0) + 1
+    if "ours" in owners:
+        ours.append((kind, [f for _, fr in access for f in fr[:3]]))
+print("%d reports; by kind and by the module of the code that made the accesses:" % len(reports))
+for (kind, own), n in sorted(by_kind.items(), key=lambda kv: -kv[1]):
+    print("  %4d  %-44s accesses in: %s" % (n, kind, ", ".join(own)))
+both_ours = sum(n for (kind, own), n in by_kind.items() if set(own) == {"ours"})
+print("%d report(s) with an access made by the library's or the driver's own code; %d with BOTH accesses there (a race of "
+      "this code with itself)" % (len(ours), both_ours))
+for kind, fr in ours[:10]:
+    print("   " + kind)
     for f in fr:
-        print("        " + f[:200])
-last = [ln for ln in txt.splitlines() if "SANITIZE DRIVER" in ln or "decode their message" in ln or "hashed calls resolved" in ln]
-print("\n".join(last))
+        print("        " + f[:220])
+print("\n".join(ln for ln in txt.splitlines() if "SANITIZE DRIVER" in ln or "decode their message" in ln or "hashed calls resolved" in ln))
