@@ -377,7 +377,8 @@ def slim(d):
             "host_threads": d["host_threads"], "cpus_pinned_to": d.get("cpus_pinned_to"),
             "host_pool_workers": d.get("host_pool_workers"), "decoded_ok": d["decoded_ok"],
             "false_decodes": d["false_decodes"], "gathered_over": d["config"]["gathered_over"],
-            "gather_ms_per_step": d.get("gather_ms_per_step"), "child_wall_s": d["child_wall_s"]}
+            "gather_ms_per_step": d.get("gather_ms_per_step"), "gather_cpu_ms_per_step": d.get("gather_cpu_ms_per_step"),
+            "child_wall_s": d["child_wall_s"]}
 
 
 def share_of_8_block(args, inflight):
@@ -411,9 +412,16 @@ def shard_block(args, full_host):
     vals = [v["value"] for v in (blk["full_host"], blk["share_of_8"], blk["rccl_world_1"], blk["rccl_world_1_share_of_8"]) if "value" in v]
     if len(vals) == 4:
         blk["share_of_8_over_full_host"] = blk["share_of_8"]["value"] / blk["full_host"]["value"]
+        # what the fan-in costs: in the rank's throughput (with it / without it), in CPU time of the driving thread per
+        # step, and -- not a cost but a latency: the thread sleeps while its copies and the collective wait their turn
+        # in the GPU's queues -- in that thread's wall time
+        blk["with_gather_over_without"] = {"full_host": blk["rccl_world_1"]["value"] / blk["full_host"]["value"],
+                                           "share_of_8": blk["rccl_world_1_share_of_8"]["value"] / blk["share_of_8"]["value"]}
         g = blk["rccl_world_1_share_of_8"]
+        if g.get("gather_cpu_ms_per_step") is not None:
+            blk["gather_cpu_fraction_of_a_step"] = g["gather_cpu_ms_per_step"] / g["ms_per_step"]
         if g.get("gather_ms_per_step") is not None:
-            blk["gather_fraction_of_a_step"] = g["gather_ms_per_step"] / g["ms_per_step"]
+            blk["gather_wall_fraction_of_a_step_of_the_driving_thread"] = g["gather_ms_per_step"] / g["ms_per_step"]
         blk["expected_8_gpu_aggregate_configs3"] = 8 * min(vals)
     return blk
 
@@ -780,7 +788,7 @@ def main():
                 decs[k].decode(I, Q)
             return k, w.last_timings()                   # timings of THIS step, read on the lane that ran it
 
-        gather_s = [0.0, 0]                                  # seconds spent in the fan-in, gathers
+        gather_s = [0.0, 0, 0.0]                             # seconds in the fan-in (wall), gathers, CPU seconds of the driving thread
 
         def run_steps(n):
             """n steps, at most `inflight` of them running; spot records are gathered in step order."""
@@ -790,21 +798,24 @@ def main():
                 if len(pending) >= inflight:
                     done, tim = pending.pop(0).result()
                     if use_dist:
-                        t_g = time.perf_counter()
+                        t_g, c_g = time.perf_counter(), time.thread_time()
                         gatherers[done].stage()               # results copied out: the lane is free again
                         gather_s[0] += time.perf_counter() - t_g
+                        gather_s[2] += time.thread_time() - c_g
                 pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
                 if done is not None and use_dist:
-                    t_g = time.perf_counter()
+                    t_g, c_g = time.perf_counter(), time.thread_time()
                     last = gatherers[done].exchange()         # every rank's records land on rank 0 (RCCL)
                     gather_s[0] += time.perf_counter() - t_g
+                    gather_s[2] += time.thread_time() - c_g
                     gather_s[1] += 1
             for fut in pending:
                 lastk, tim = fut.result()
                 if use_dist:
-                    t_g = time.perf_counter()
+                    t_g, c_g = time.perf_counter(), time.thread_time()
                     last = gatherers[lastk].gather()
                     gather_s[0] += time.perf_counter() - t_g
+                    gather_s[2] += time.thread_time() - c_g
                     gather_s[1] += 1
             return last, tim, lastk
 
@@ -815,7 +826,7 @@ def main():
 
         def timed(n):
             fence()
-            gather_s[0], gather_s[1] = 0.0, 0
+            gather_s[0], gather_s[1], gather_s[2] = 0.0, 0, 0.0
             t0 = time.perf_counter()
             out = run_steps(n)
             fence()
@@ -849,7 +860,8 @@ def main():
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
                 "timings": timings,
                 # the fan-in of the timed steps as the driving thread saw it (staging copy + H2D + gather + D2H on rank 0)
-                "gather_ms_per_step": (1e3 * gather_s[0] / gather_s[1]) if gather_s[1] else None}
+                "gather_ms_per_step": (1e3 * gather_s[0] / gather_s[1]) if gather_s[1] else None,
+                "gather_cpu_ms_per_step": (1e3 * gather_s[2] / gather_s[1]) if gather_s[1] else None}
 
     nseg = args.segments or {2: 1024, 3: 8192, 4: 8192, 5: 1024}[args.config]
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
@@ -902,7 +914,7 @@ def main():
                                    "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
                                              pm["calibration"]["true_bytes_per_counted_read_byte"],
                                              pm["calibration"]["true_bytes_per_counted_written_byte"]))
-            for name in (() if traffic else ("r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
+            for name in (() if traffic else ("r05_k1_pmc_traffic.json", "r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
                 tf = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tf):
                     jd = json.load(open(tf))
@@ -1058,7 +1070,7 @@ def main():
                                                          "step; counts: sum over its slots"),
             "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
             "cpus_pinned_to": len(os.sched_getaffinity(0)) if args.cpu_share else None,
-            "gather_ms_per_step": m.get("gather_ms_per_step"),
+            "gather_ms_per_step": m.get("gather_ms_per_step"), "gather_cpu_ms_per_step": m.get("gather_cpu_ms_per_step"),
             "host": {"hw_threads": os.cpu_count(), "usable_cpus": usable_cpus()},
             "host_pool_workers": int(L.wspr_host_pool_workers()),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,

@@ -63,6 +63,7 @@ static void host_wait(hipEvent_t ev) {
         return;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    static const long nap_cap_ns = [] { const char* e = lab_env("WSPR_NAP_US"); return e ? atol(e) * 1000L : 250000L; }();
     long nap_ns = 20000;
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
@@ -71,7 +72,7 @@ static void host_wait(hipEvent_t ev) {
         if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(t_spin_us)) { __builtin_ia32_pause(); continue; }
         timespec ts{0, nap_ns};
         nanosleep(&ts, nullptr);
-        nap_ns = std::min(nap_ns * 2, 250000L);
+        nap_ns = std::min(nap_ns * 2, nap_cap_ns);
     }
 }
 
