@@ -63,7 +63,7 @@ static void host_wait(hipEvent_t ev) {
         return;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    static const long nap_cap_ns = [] { const char* e = lab_env("WSPR_NAP_US"); return e ? atol(e) * 1000L : 250000L; }();
+    constexpr long nap_cap_ns = 250000L;        // 60 / 120 / 250 / 500 / 1000 us measured alike (profiles/r05_sleep_cap_ab.txt)
     long nap_ns = 20000;
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
