@@ -29,8 +29,35 @@
 #include <vector>
 
 #include "wspr_message.h"
+#include "../kernels/glibc_sincosf.h"
 
 namespace wspr {
+
+// The device's sinf / cosf restate the FMA3 build of glibc's routine, which x86-64 glibc selects on every CPU that has
+// FMA3 -- any host an MI355X sits in.  On a host whose libm is the SSE2 build the reference itself would compute 34 of
+// the 2^32 inputs differently (one ulp; all of them |x| > 17, i.e. phases of the subtraction's reference signal): the
+// host-side constant tables would follow that libm, the kernels would not.  Checked once, on six of the 34 inputs
+// (found by an exhaustive scan of both builds); a mismatch is reported loudly instead of being left to a parity test.
+static void check_host_libm_once() {
+    static const bool done = [] {
+        static const uint32_t probe[6] = {0x418a3adbu, 0x41bc76d9u, 0x4202eb4bu, 0x4255b0a9u, 0x42a35c07u, 0x42cf5854u};
+        int bad = 0;
+        for (uint32_t b : probe) {
+            float x;
+            memcpy(&x, &b, 4);
+            volatile float hx = x;                              // keep the calls out of constant folding
+            const float hs = sinf(hx), hc = cosf(hx);
+            const float ds = glibc_sinf(x), dc = glibc_cosf(x);
+            bad += (memcmp(&hs, &ds, 4) != 0) + (memcmp(&hc, &dc, 4) != 0);
+        }
+        if (bad)
+            fprintf(stderr, "libwspr_mi355x: WARNING: this host's libm computes sinf/cosf with its non-FMA build (%d of 12 probe "
+                            "values differ): the kernels reproduce the FMA build; rebuild with -DWSPR_SINCOS_FMA=0 for "
+                            "bit-exact agreement with a reference running on this host (34 of 2^32 inputs are affected)\n", bad);
+        return true;
+    }();
+    (void)done;
+}
 
 #define HIP_OK(expr)                                                                         \
     do {                                                                                     \
@@ -310,6 +337,7 @@ static void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
 }
 
 Context::Context(int nslots) : d(new Impl) {
+    check_host_libm_once();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");

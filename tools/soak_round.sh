@@ -9,3 +9,5 @@ O=${1:-gpurun_out/soak}; mkdir -p $O
 ( time python tools/crowded_soak.py ) > $O/crowded_trace_48x4.txt 2>&1
 ( time python tools/raw_soak.py 6 4100 ) > $O/raw_soak_6.txt 2>&1
 tail -n 6 $O/*.txt
+( time WSPR_HASH_SEGMENTS=1536 WSPR_HASH_SEED=5 python -m pytest tests/test_gpu_hashtable.py -q -x -s -k "0.05" ) > $O/hashtable_1536_segments.txt 2>&1
+tail -n 4 $O/hashtable_1536_segments.txt
