@@ -547,6 +547,33 @@ def hashtable_block(dev, lanes):
         warm = min(lane.submit(call, 1).result() for _ in range(3))
         unresolved_warm = sum(1 for s in range(nseg) for i in range(nres[s]) if out[s * K + i].message.startswith(b"<...>"))
         entries = sum(1 for _ in open("hashtable.txt"))
+        # ... and several such calls IN FLIGHT (twelve lanes, one pipeline each): a call runs its first round ahead of its
+        # turn, then takes the file its predecessors wrote as its base and decodes again what that changes
+        nfl = min(12, len(lanes))
+        outs = [((w.decoder_results * (nseg * K))(), (C.c_int * nseg)()) for _ in range(nfl)]
+        for ex in lanes[:nfl]:
+            ex.submit(L.wspr_set_thread_slots, 1).result()
+
+        def call_on(k, use):
+            o = w.default_options()
+            o.usehashtable = use
+            oo, nn = outs[k]
+            assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), o, C.addressof(oo), K, C.addressof(nn)) == 0
+
+        def flight(use, n):
+            pend = []
+            for s in range(n):
+                if len(pend) >= nfl:
+                    pend.pop(0).result()
+                pend.append(lanes[s % nfl].submit(call_on, s % nfl, use))
+            for f in pend:
+                f.result()
+        rates = {}
+        for use in (0, 1):
+            flight(use, nfl)
+            t0 = time.perf_counter()
+            flight(use, 2 * nfl)
+            rates[use] = nseg * 2 * nfl / (time.perf_counter() - t0)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
@@ -561,6 +588,10 @@ def hashtable_block(dev, lanes):
             "with_option_file_of_the_previous_call": {"value": nseg / warm, "unit": "segments/s", "ms_per_call": 1e3 * warm,
                                                       "of_without_option": plain / warm,
                                                       "unresolved_hashed_calls": unresolved_warm},
+            "calls_in_flight": {"lanes": nfl, "without_option": {"value": rates[0], "unit": "segments/s"},
+                                "with_option": {"value": rates[1], "unit": "segments/s", "of_without_option": rates[1] / rates[0]},
+                                "note": "the file of the earlier calls is in place (steady state); calls enter in "
+                                        "submission order and commit in that order"},
             "hashtable_entries": entries}
 
 

@@ -97,7 +97,8 @@ int wspr_decode(float *idat, float *qdat, int samples, struct decoder_options op
  * modified unless writeback != 0.  With options.usehashtable the hash memory orders the segments
  * (wsprd.c:481-494, 842-852): the result -- spots and hashtable.txt -- is that of nseg reference calls in index
  * order, obtained in parallel (see wspr_decode_batch_hashed() below; rounds 2-4 decoded such a batch one segment at a
- * time).  Calls with the option take turns, as each reads the file the previous one wrote. */
+ * time).  Calls with the option are ordered as they enter the library (each reads the file the previous one wrote);
+ * a call decodes its first round ahead of its turn, so several may be in flight on different lanes. */
 int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results *decodes,
                       int max_results, int *n_results, int writeback);

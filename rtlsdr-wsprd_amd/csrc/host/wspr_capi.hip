@@ -6,11 +6,13 @@
 #include <algorithm>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
 #include <ctime>
 #include <new>
 #include <vector>
@@ -68,7 +70,8 @@ namespace {
 template <class Load, class Reload>
 int decode_split(int nseg, int samples, const decoder_options& options, decoder_results* decodes, int max_results,
                  int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
-                 wspr_trace* trace = nullptr, wspr::HashBatch* hb = nullptr, const std::vector<int>* revisit = nullptr) {
+                 wspr_trace* trace = nullptr, wspr::HashBatch* hb = nullptr, const std::vector<int>* revisit = nullptr,
+                 const std::function<void()>& before_validation = nullptr) {
     const int nslots = (nseg >= 128) ? Context::slot_cap() : 1;
     Context::note_slots_used(nslots);
     Context& c0 = Context::get();
@@ -119,6 +122,7 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
         ++hb->rounds; hb->redecoded += (int)revisit->size();
         again(*revisit);
     }
+    if (hb && before_validation) before_validation();      // e.g. wait for the calls before this one, take their file as the base
     if (hb)
         for (;;) {
             hb->rebuild();
@@ -135,8 +139,34 @@ int decode_split(int nseg, int samples, const decoder_options& options, decoder_
     return 0;
 }
 
-// usehashtable: calls are ordered by definition (each reads the file the previous one wrote), so they take turns
-std::mutex& hash_file_turn() { static std::mutex m; return m; }
+// usehashtable: calls are ordered by definition -- each reads the file the previous one wrote.  The order is the order
+// in which they ENTER (a ticket), and a call's turn comes when every earlier ticket has left.  A batch call decodes its
+// first round BEFORE its turn (against the file as it is then: speculation, beside the calls ahead of it on other
+// lanes), waits, takes the file its predecessors have written as its base, decodes again what that changes, writes the
+// file and leaves; single calls and the sharded form simply wait for their turn first.
+struct HashChain {
+    std::mutex m;
+    std::condition_variable cv;
+    unsigned long next = 0, serving = 0;
+    static HashChain& get() { static HashChain c; return c; }
+    struct Ticket {
+        HashChain& c;
+        unsigned long t;
+        bool left = false;
+        explicit Ticket(HashChain& c_) : c(c_) { std::lock_guard<std::mutex> g(c.m); t = c.next++; }
+        void wait_turn() { std::unique_lock<std::mutex> g(c.m); c.cv.wait(g, [&] { return c.serving == t; }); }
+        void leave() {
+            if (left) return;
+            wait_turn();
+            { std::lock_guard<std::mutex> g(c.m); ++c.serving; }
+            left = true;
+            c.cv.notify_all();
+        }
+        ~Ticket() { leave(); }                               // whatever happened: the calls behind must not wait for ever
+        Ticket(const Ticket&) = delete;
+        Ticket& operator=(const Ticket&) = delete;
+    };
+};
 }  // namespace
 
 namespace {
@@ -163,8 +193,12 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
                   int* n_results, Load load, Reload reload, bool writeback, float* idat, float* qdat, size_t seg_stride,
                   int seg_index0, const wspr_hash_op* prior, int n_prior, int flags, wspr_hash_op* stores_out, int cap,
                   int* n_stores, int* n_redecoded) {
-    std::lock_guard<std::mutex> turn(hash_file_turn());
+    HashChain::Ticket ticket(HashChain::get());
     const bool revisit = (flags & WSPR_HASH_REVISIT) != 0;
+    // a plain batch call (all of its job in one call, the file its own to write) may run its first round ahead of its
+    // turn; a shard of a larger job is driven round by round from outside and waits first
+    const bool ahead = !revisit && !(flags & WSPR_HASH_KEEP_FILE) && n_prior <= 0;
+    if (!ahead) ticket.wait_turn();
     if (revisit && !(t_hash && (int)t_hash->log.size() == nseg && t_hash->seg0 == seg_index0))
         throw std::runtime_error("WSPR_HASH_REVISIT without a matching previous call on this thread");
     if (!revisit) {
@@ -180,7 +214,8 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
     std::vector<int> todo;
     if (revisit) { hb.rebuild(); todo = hb.invalid(); }
     decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, writeback, idat, qdat, seg_stride,
-                 nullptr, &hb, revisit ? &todo : nullptr);
+                 nullptr, &hb, revisit ? &todo : nullptr,
+                 ahead ? std::function<void()>([&] { ticket.wait_turn(); hb.load_file(); }) : std::function<void()>());
     if (!(flags & WSPR_HASH_KEEP_FILE)) hb.commit_file();
     const std::vector<wspr::HashOp> st = hb.stores();
     if (n_stores) *n_stores = (int)st.size();
@@ -210,6 +245,9 @@ int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t se
         return wspr_decode_batch_hashed(idat, qdat, nseg, samples, seg_stride, options, decodes, max_results, n_results,
                                         writeback, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
     try {
+        // a single call with the option reads and writes hashtable.txt itself (wsprd.c:481-494, 842-852): in its turn
+        std::unique_ptr<HashChain::Ticket> turn;
+        if (options.usehashtable) { turn.reset(new HashChain::Ticket(HashChain::get())); turn->wait_turn(); }
         if (samples > wspr::kMaxSamples) {
             // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
             // its callers hold; this library's working rows are 45 000 samples, so a longer record is refused, not cut
@@ -259,7 +297,8 @@ int wspr_decode_batch_hashed(float* idat, float* qdat, int nseg, int samples, si
 
 int wspr_hash_commit(const wspr_hash_op* stores, int n) {
     try {
-        std::lock_guard<std::mutex> turn(hash_file_turn());
+        HashChain::Ticket ticket(HashChain::get());
+        ticket.wait_turn();
         wspr::HashBatch hb;
         hb.load_file();
         wspr::HashBatch::commit_file(hb.base_call, hb.base_grid, reinterpret_cast<const wspr::HashOp*>(stores), (size_t)std::max(0, n));
@@ -322,6 +361,8 @@ int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, i
         if (options.usehashtable && nseg > 1)             // the hash memory orders the segments: parallel all the same
             return decode_hashed(nseg, samples, options, decodes, max_results, n_results, load, reload, false, nullptr, nullptr,
                                  seg_stride, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
+        std::unique_ptr<HashChain::Ticket> turn;
+        if (options.usehashtable) { turn.reset(new HashChain::Ticket(HashChain::get())); turn->wait_turn(); }
         return decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, false, nullptr, nullptr, seg_stride);
     } catch (const std::exception& e) {
         for (int s = 0; s < nseg; ++s) n_results[s] = 0;

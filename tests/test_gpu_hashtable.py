@@ -198,3 +198,43 @@ def test_sharded_hashed_calls_equal_one_batch(w, tmp_path):
     (sharded, rounds), sf = _in_dir(tmp_path / "sharded", job)
     print("sharded -H: %d rounds" % rounds)
     assert sharded == whole and sf == wf and rounds >= 2
+
+
+def test_hashed_calls_in_flight_keep_their_order(w, tmp_path):
+    """Calls with the option are ordered by definition (each reads the file the previous one wrote): their order is the
+    order in which they enter the library.  Since round 5 they need not wait for each other to START: a call decodes its
+    first round ahead of its turn, beside the calls before it on other lanes, then waits, takes the file they wrote as its
+    base and decodes again what that changes.  Four batches of 224 segments on four lanes, submitted 30 ms apart (each
+    takes longer than that, so they overlap): spots and hashtable.txt equal the oracle walking all 896 segments in order."""
+    import time
+    nb, per = 4, 224
+    I, Q, _ = _traffic(nb * per, 0.3, 4242)
+    L = w.lib()
+    lanes = [ThreadPoolExecutor(1) for _ in range(nb)]
+    for k, ex in enumerate(lanes):
+        ex.submit(L.wspr_bind_thread_lane, 8 + k).result()
+
+    def one(k):
+        t0 = time.perf_counter()
+        got = w.wspr_decode_batch(I[k * per:(k + 1) * per], Q[k * per:(k + 1) * per], _opt(w, 1), max_results=16)
+        return [[_tup(x) for x in g] for g in got], t0, time.perf_counter()
+
+    def job():
+        futs = []
+        for k in range(nb):
+            futs.append(lanes[k].submit(one, k))
+            time.sleep(0.03)
+        res = [f.result() for f in futs]
+        overlap = sum(1 for k in range(1, nb) if res[k][1] < res[k - 1][2])     # started before its predecessor ended
+        return [sp for r in res for sp in r[0]], overlap
+
+    def oracle():
+        o = ol.default_options()
+        o.usehashtable = 1
+        return [[_tup(x) for x in ol.decode(I[s], Q[s], NS, o)[0]] for s in range(nb * per)]
+    (got, overlap), gf = _in_dir(tmp_path / "flight", job)
+    ref, rf = _in_dir(tmp_path / "oracle", oracle)
+    strip = lambda res: [[t[:8] + t[9:] for t in seg] for seg in res]
+    assert strip(got) == strip(ref) and gf == rf
+    print("calls in flight: %d of %d started before their predecessor had returned" % (overlap, nb - 1))
+    assert overlap >= 2
