@@ -569,7 +569,10 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
         // into a dense device buffer, and the row kernel that also serves resident input spreads them into the working
         // layout (device to device, microseconds).  A strided host-to-device copy straight into the working rows measured
         // 40-45 GB/s against 55 for the linear one (round 5).
-        if ((samples & 3) == 0 && (stride & 3) == 0 && !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
+        // (rows far apart -- a stride of more than twice the record -- would make a linear copy carry the gaps: those
+        // take the strided copy below)
+        if ((samples & 3) == 0 && (stride & 3) == 0 && stride <= 2 * (size_t)samples &&
+            !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
             constexpr int kDense = 256;
             const int per = std::min(nseg, kDense);
             // two dense buffers in turn: the row kernel of chunk k runs under the DMA of chunk k + 1

@@ -315,3 +315,54 @@ def test_two_lanes_with_fano_split_and_memo(env):
         for spots, tm in out[k]:
             assert spots == exact[k], k
             assert tm["fano_left_to_device"] > 100 and tm["segments_redecoded"] > 10
+
+
+def test_host_buffer_entry_paths_agree(env):
+    """wspr_decode_batch() from HOST memory (the reference's calling convention, wsprd.h:106-111) by every route of
+    load_host(): pageable rows through the pinned chunk ring (150 segments = chunks of 64 + 64 + 22), the same rows pinned
+    with wspr_pin_host_buffer() (linear DMA + row kernel), rows far apart (a stride of three records: the strided copy),
+    a shorter record after a longer one (the chunks' tails must be zero again), and write-back of the residual -- all
+    equal to the resident call on the same segments."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    nseg = 150
+    I, Q, _ = bench.synth_batch_gpu(nseg, 515, dev, 2, -12.0, -18.0, 0.5)
+    res = w.BatchDecoder(nseg, 16)
+    res.decode(I, Q)
+    want = [[_tup(x) for x in res.spots(s)] for s in range(nseg)]
+    Ih, Qh = I.cpu().numpy().copy(), Q.cpu().numpy().copy()
+
+    def host(Ia, Qa, samples, stride, writeback=0, n=nseg):
+        out = (w.decoder_results * (n * 16))(); cnt = (C.c_int * n)()
+        assert L.wspr_decode_batch(ol.ptr(Ia), ol.ptr(Qa), n, samples, stride, w.default_options(), C.addressof(out), 16,
+                                   C.addressof(cnt), writeback) == 0
+        return [[_tup(out[s * 16 + i]) for i in range(cnt[s])] for s in range(n)]
+    assert host(Ih, Qh, NS, NS) == want                                      # pageable
+    assert L.wspr_pin_host_buffer(ol.ptr(Ih), Ih.nbytes) == 0 and L.wspr_pin_host_buffer(ol.ptr(Qh), Qh.nbytes) == 0
+    try:
+        assert host(Ih, Qh, NS, NS) == want                                  # pinned, dense rows
+        # a shorter record (44 544 samples = 87 FFT blocks): resident vs pinned vs pageable, after the longer one
+        short = 44544
+        rs = w.BatchDecoder(nseg, 16)
+        rs.decode_ptr(I.data_ptr(), Q.data_ptr(), short, I.stride(0))
+        want_short = [[_tup(x) for x in rs.spots(s)] for s in range(nseg)]
+        assert host(Ih, Qh, short, NS) == want_short
+    finally:
+        assert L.wspr_unpin_host_buffer(ol.ptr(Ih)) == 0 and L.wspr_unpin_host_buffer(ol.ptr(Qh)) == 0
+    assert host(Ih, Qh, short, NS) == want_short                             # pageable again, shorter than the chunks' last fill
+    assert host(Ih, Qh, NS, NS) == want
+    # rows far apart: stride = 3 records (pageable: gathered row by row; pinned: the strided copy)
+    wide_i = np.zeros((40, 3 * NS), np.float32); wide_q = np.zeros((40, 3 * NS), np.float32)
+    wide_i[:, :NS] = Ih[:40]; wide_q[:, :NS] = Qh[:40]
+    assert host(wide_i, wide_q, NS, 3 * NS, n=40) == want[:40]
+    assert L.wspr_pin_host_buffer(ol.ptr(wide_i), wide_i.nbytes) == 0 and L.wspr_pin_host_buffer(ol.ptr(wide_q), wide_q.nbytes) == 0
+    try:
+        assert host(wide_i, wide_q, NS, 3 * NS, n=40) == want[:40]
+    finally:
+        L.wspr_unpin_host_buffer(ol.ptr(wide_i)); L.wspr_unpin_host_buffer(ol.ptr(wide_q))
+    # write-back: the residual after subtraction comes back into the caller's rows, equal for pageable and single calls
+    Iw, Qw = Ih[:20].copy(), Qh[:20].copy()
+    assert host(Iw, Qw, NS, NS, writeback=1, n=20) == want[:20]
+    for s in (0, 7, 19):
+        _, ri, rq = w.wspr_decode(Ih[s], Qh[s], NS)
+        assert np.array_equal(Iw[s], ri) and np.array_equal(Qw[s], rq)
