@@ -1541,6 +1541,44 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
     }
 }
 
+// What unpacking a decoded 50-bit message and re-encoding its text yield is a pure function of the bits as long as no
+// hash look-up is involved (types 1 and 2; a type 3 asks the table): texts, the "noprint" flag, the stores into the
+// hash memory (unpk_'s and those of the re-unpack inside get_wspr_channel_symbols) and the 162 channel symbols.  A
+// receiver hears the same stations slot after slot, a batch holds thousands of copies of a few hundred messages, and
+// this host work (a dozen snprintf, the convolutional encoder, the interleaver: ~1.2 us) is most of what a rank with
+// few CPUs spends per decode.  Per host thread: the first occurrence is computed through a recording view of the
+// segment's table, later ones replay the stores into THEIR segment's table and copy the rest.
+namespace {
+struct MsgMemo {
+    struct Put { int slot; bool has_grid; char call[13]; char grid[5]; };
+    struct Entry {
+        int noprint = 0;
+        char clp[23], call[13], loc[7], pwr[3], callsign[13];
+        std::vector<Put> unpack_puts, chan_puts;
+        int chan_state = 0;                          // 0 not asked yet, 1 symbols valid, 2 the text does not encode
+        unsigned char sym[kNSymD];
+    };
+    std::unordered_map<uint64_t, Entry> map;
+};
+struct RecordingTable : HashTable {
+    HashTable& t;
+    std::vector<MsgMemo::Put>& puts;
+    bool looked_up = false;
+    RecordingTable(HashTable& t_, std::vector<MsgMemo::Put>& p) : t(t_), puts(p) {}
+    const char* call_at(int slot) override { looked_up = true; return t.call_at(slot); }
+    const char* peek(int slot) override { return t.peek(slot); }
+    void put(int slot, const char* call, const char* grid) override {
+        MsgMemo::Put p{};
+        p.slot = slot; p.has_grid = grid != nullptr;
+        snprintf(p.call, sizeof p.call, "%s", call);
+        if (grid) snprintf(p.grid, sizeof p.grid, "%s", grid);
+        puts.push_back(p);
+        t.put(slot, call, grid);
+    }
+};
+thread_local MsgMemo t_msg_memo;
+}  // namespace
+
 // Host bookkeeping in candidate order (wsprd.c:768-822).  Items of one segment are contiguous in the
 // wave and must be handled in order; different segments are independent -> one pool task per segment.
 // Returns the subtraction jobs of the wave.
@@ -1592,10 +1630,45 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         FlatHashTable flat(hashtab_of(s), loctab_of(s), &bk.dirty);
         std::unique_ptr<SegHashView> shared(hb ? new SegHashView(hb, hb_off + s) : nullptr);
         HashTable& tab = hb ? static_cast<HashTable&>(*shared) : static_cast<HashTable&>(flat);
-        const int noprint = unpack_message(message, tab, call_loc_pow, call, loc, pwr, callsign);
+        // (memo: see MsgMemo above; a message that looks the table up -- type 3 -- is computed every time)
+        uint64_t mkey = 0;
+        for (int k = 0; k < 7; ++k) mkey = (mkey << 8) | w.decdata[k];
+        MsgMemo& mm = t_msg_memo;
+        if (mm.map.size() > 200000) mm.map.clear();
+        auto mit = mm.map.find(mkey);
+        int noprint;
+        if (mit != mm.map.end()) {
+            const MsgMemo::Entry& e = mit->second;
+            noprint = e.noprint;
+            memcpy(call_loc_pow, e.clp, sizeof e.clp); memcpy(call, e.call, sizeof e.call); memcpy(loc, e.loc, sizeof e.loc);
+            memcpy(pwr, e.pwr, sizeof e.pwr); memcpy(callsign, e.callsign, sizeof e.callsign);
+            for (const MsgMemo::Put& p : e.unpack_puts) tab.put(p.slot, p.call, p.has_grid ? p.grid : nullptr);
+        } else {
+            MsgMemo::Entry e;
+            RecordingTable rec(tab, e.unpack_puts);
+            noprint = unpack_message(message, rec, call_loc_pow, call, loc, pwr, callsign);
+            if (!rec.looked_up) {
+                e.noprint = noprint;
+                memcpy(e.clp, call_loc_pow, sizeof e.clp); memcpy(e.call, call, sizeof e.call); memcpy(e.loc, loc, sizeof e.loc);
+                memcpy(e.pwr, pwr, sizeof e.pwr); memcpy(e.callsign, callsign, sizeof e.callsign);
+                mit = mm.map.emplace(mkey, std::move(e)).first;
+            }
+        }
+        auto symbols_of = [&](unsigned char* sym) -> int {          // get_wspr_channel_symbols(call_loc_pow, ...)
+            if (mit == mm.map.end()) return channel_symbols(call_loc_pow, tab, sym);
+            MsgMemo::Entry& e = mit->second;
+            if (e.chan_state == 0) {
+                RecordingTable rec(tab, e.chan_puts);
+                e.chan_state = channel_symbols(call_loc_pow, rec, e.sym) ? 1 : 2;
+            } else {
+                for (const MsgMemo::Put& p : e.chan_puts) tab.put(p.slot, p.call, p.has_grid ? p.grid : nullptr);
+            }
+            if (e.chan_state == 1) memcpy(sym, e.sym, kNSymD);
+            return e.chan_state == 1;
+        };
         if (opt.subtraction && ipass == 0 && !noprint) {
             SubJob jb{};
-            if (channel_symbols(call_loc_pow, tab, jb.sym)) {
+            if (symbols_of(jb.sym)) {
                 jb.seg = s; jb.f0 = w.fine.freq; jb.shift = w.fine.shift; jb.drift = w.fine.drift;
                 job_of[i] = jb;
                 has_job[i] = 1;

@@ -68,7 +68,8 @@ def test_product_reads_five_environment_variables_and_no_kernel_switch():
     assert not [k for k in switches if k in prod]
     assert all(k in lab for k in switches)
     names = set(re.findall(rb"WSPR_[A-Z0-9_]+", prod))
-    assert names <= set(knobs) | {b"WSPR_HASH_REVISIT"}, names
+    # (besides the knobs: a flag name in an error text, and the build macro the libm warning tells the user about)
+    assert names <= set(knobs) | {b"WSPR_HASH_REVISIT", b"WSPR_SINCOS_FMA"}, names
 
 
 def test_set_device_rejects_devices_that_do_not_exist():
