@@ -1634,7 +1634,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         uint64_t mkey = 0;
         for (int k = 0; k < 7; ++k) mkey = (mkey << 8) | w.decdata[k];
         MsgMemo& mm = t_msg_memo;
-        if (mm.map.size() > 200000) mm.map.clear();
+        if (mm.map.size() > 20000) mm.map.clear();                 // a few MB per host thread at most
         auto mit = mm.map.find(mkey);
         int noprint;
         if (mit != mm.map.end()) {
