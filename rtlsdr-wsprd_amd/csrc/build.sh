@@ -30,12 +30,14 @@ compile_variant() {
       pids+=($!)
     fi
   done
-  o="$objdir/wspr_message.o"
-  objs+=("$o")
-  if [ ! -f "$o" ] || [ "$here/host/wspr_message.cpp" -nt "$o" ] || [ -n "$(find "$here/host" -name '*.h' -newer "$o" | head -1)" ]; then
-    g++ -O3 -mpopcnt -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-format-truncation $extra -c "$here/host/wspr_message.cpp" -o "$o" &
-    pids+=($!)
-  fi
+  for s in wspr_message wspr_hashmem; do            # pure host C++ (no HIP): the message layer, the batch hash memory
+    o="$objdir/$s.o"
+    objs+=("$o")
+    if [ ! -f "$o" ] || [ "$here/host/$s.cpp" -nt "$o" ] || [ -n "$(find "$here/host" -name '*.h' -newer "$o" | head -1)" ]; then
+      g++ -O3 -mpopcnt -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-format-truncation $extra -c "$here/host/$s.cpp" -o "$o" &
+      pids+=($!)
+    fi
+  done
   for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 }
 

@@ -12,6 +12,7 @@
 #include "../../../include/wspr_mi355x.h"
 #include "../../../include/wspr_mi355x_bench.h"   // declarations only: the definitions exist in the lab build (-DWSPR_LAB)
 #include "../kernels/wspr_device.h"
+#include "wspr_hashmem.h"
 
 namespace wspr {
 
@@ -48,48 +49,6 @@ struct FanoMemo {
         const auto it = map.find(std::string(reinterpret_cast<const char*>(sym), 162));
         return it == map.end() ? nullptr : &it->second;
     }
-};
-
-// ---- usehashtable on a batch -------------------------------------------------------------------------
-// The reference's hash memory (hashtable.txt read before, written after every decode: wsprd.c:481-494, 842-852) orders
-// the segments: what a type-3 "<call>" message resolves to (wsprd_utils.c:296-300) depends on what was heard before.
-// A batch is nevertheless decoded IN PARALLEL: every segment sees the memory through a view (SegHashView) that
-//   * answers a look-up from the segment's own earlier stores, else from the stores of EARLIER segments as currently
-//     known (empty in the first round), else from the table loaded from the file -- and logs what it answered;
-//   * logs the segment's stores in order.
-// Afterwards the logs are checked in index order: a segment whose logged look-ups still get the same answers from its
-// predecessors' (now known) stores is exactly what the serial walk would have produced -- its decode is a function of
-// its samples and those answers alone; the others are decoded again against the updated memory, round by round, until
-// none is left (segment k is final after round k at the latest; in practice after one or two).
-struct HashOp {
-    int32_t seg;        // global segment index
-    int32_t slot;       // 0 .. 32767
-    int32_t kind;       // 1 = type-1 store (call + locator), 2 = type-2 store (call only), 3 = look-up answered by the base
-    char call[13];      // stored call, or the answer the look-up got ("" = none)
-    char grid[5];
-    char pad[2];
-};
-static_assert(sizeof(HashOp) == 32, "HashOp is exchanged between ranks as raw bytes");
-
-struct HashBatch {
-    int seg0 = 0;                                   // global index of this call's first segment
-    std::vector<char> base_call, base_grid;         // the file as loaded: [32768][13], [32768][5]
-    std::vector<HashOp> prior;                      // stores of segments outside this call (other shards), ascending seg
-    std::vector<std::vector<HashOp>> log;           // per segment of this call: its stores and base look-ups, in order
-    struct Ver { int32_t seg; char call[13]; };
-    std::vector<std::vector<Ver>> ver;              // per slot: last store of each storing segment, ascending seg
-    std::vector<int> touched;                       // slots with versions
-    int rounds = 0, redecoded = 0;
-
-    HashBatch();
-    void load_file();                               // hashtable.txt of the working directory (wsprd.c:481-494)
-    void resize(int nseg) { log.assign((size_t)nseg, {}); }
-    void rebuild();                                 // ver := prior + log
-    const char* lookup(int slot, int gseg) const;   // what segment gseg finds at slot from its predecessors / the file
-    std::vector<int> invalid() const;               // local indices of segments with a look-up that would now differ
-    std::vector<HashOp> stores() const;             // this call's stores in segment order
-    static void commit_file(const std::vector<char>& call0, const std::vector<char>& grid0, const HashOp* w, size_t n);
-    void commit_file() const;                       // file := base + prior + this call's stores (wsprd.c:842-852)
 };
 
 class Context {

@@ -771,129 +771,6 @@ void Context::fetch_candidates(int nseg, std::vector<int>& npk, std::vector<DevC
     finish_fetch_candidates(nseg, npk, cand);
 }
 
-// ------------------------------------------------------- batch hash memory ---
-HashBatch::HashBatch()
-    : base_call((size_t)kHashSlots * kHashWidth, 0), base_grid((size_t)kHashSlots * kLocWidth, 0), ver((size_t)kHashSlots) {}
-
-void HashBatch::load_file() {                                     // wsprd.c:481-494
-    std::fill(base_call.begin(), base_call.end(), 0);
-    std::fill(base_grid.begin(), base_grid.end(), 0);
-    if (FILE* fh = fopen("hashtable.txt", "r+")) {
-        char line[80], hcall[13], hgrid[5];
-        int nh;
-        while (fgets(line, sizeof line, fh) != nullptr) {
-            hgrid[0] = hcall[0] = '\0';
-            if (sscanf(line, "%d %12s %4s", &nh, hcall, hgrid) < 2) continue;
-            if (nh >= 0 && nh < kHashSlots) {
-                snprintf(base_call.data() + (size_t)nh * kHashWidth, kHashWidth, "%s", hcall);
-                if (strlen(hgrid) > 0) snprintf(base_grid.data() + (size_t)nh * kLocWidth, kLocWidth, "%s", hgrid);
-            }
-        }
-        fclose(fh);
-    }
-}
-
-void HashBatch::rebuild() {
-    for (int slot : touched) ver[(size_t)slot].clear();
-    touched.clear();
-    auto add = [&](const HashOp& op) {
-        if (op.kind != 1 && op.kind != 2) return;
-        if (op.slot < 0 || op.slot >= kHashSlots) return;
-        auto& v = ver[(size_t)op.slot];
-        if (v.empty()) touched.push_back(op.slot);
-        if (v.empty() || v.back().seg != op.seg) v.emplace_back();
-        v.back().seg = op.seg;
-        memcpy(v.back().call, op.call, sizeof op.call);
-    };
-    // ascending segment order: the other shards' stores that precede this call, this call's, the ones that follow
-    size_t p = 0;
-    for (; p < prior.size() && prior[p].seg < seg0; ++p) add(prior[p]);
-    for (const auto& l : log) for (const HashOp& op : l) add(op);
-    for (; p < prior.size(); ++p) add(prior[p]);
-}
-
-const char* HashBatch::lookup(int slot, int gseg) const {
-    const auto& v = ver[(size_t)slot];
-    for (size_t i = v.size(); i-- > 0;)
-        if (v[i].seg < gseg) return v[i].call;
-    return base_call.data() + (size_t)slot * kHashWidth;
-}
-
-std::vector<int> HashBatch::invalid() const {
-    std::vector<int> out;
-    for (size_t s = 0; s < log.size(); ++s)
-        for (const HashOp& op : log[s])
-            if (op.kind == 3 && strcmp(lookup(op.slot, seg0 + (int)s), op.call) != 0) { out.push_back((int)s); break; }
-    return out;
-}
-
-std::vector<HashOp> HashBatch::stores() const {
-    std::vector<HashOp> out;
-    for (const auto& l : log) for (const HashOp& op : l) if (op.kind == 1 || op.kind == 2) out.push_back(op);
-    return out;
-}
-
-void HashBatch::commit_file(const std::vector<char>& call0, const std::vector<char>& grid0, const HashOp* w, size_t n) {
-    std::vector<char> call = call0, grid = grid0;
-    for (size_t i = 0; i < n; ++i) {
-        const HashOp& op = w[i];
-        if ((op.kind != 1 && op.kind != 2) || op.slot < 0 || op.slot >= kHashSlots) continue;
-        snprintf(call.data() + (size_t)op.slot * kHashWidth, kHashWidth, "%s", op.call);
-        if (op.kind == 1) snprintf(grid.data() + (size_t)op.slot * kLocWidth, kLocWidth, "%s", op.grid);
-    }
-    if (FILE* fh = fopen("hashtable.txt", "w")) {                 // wsprd.c:842-852
-        for (int i = 0; i < kHashSlots; ++i)
-            if (call[(size_t)i * kHashWidth] != '\0')
-                fprintf(fh, "%5d %s %s\n", i, call.data() + (size_t)i * kHashWidth, grid.data() + (size_t)i * kLocWidth);
-        fclose(fh);
-    }
-}
-
-void HashBatch::commit_file() const {
-    std::vector<HashOp> all;
-    size_t p = 0;
-    for (; p < prior.size() && prior[p].seg < seg0; ++p) all.push_back(prior[p]);
-    for (const HashOp& op : stores()) all.push_back(op);
-    for (; p < prior.size(); ++p) all.push_back(prior[p]);
-    commit_file(base_call, base_grid, all.data(), all.size());
-}
-
-namespace {
-// One segment's window on the batch's hash memory (see HashBatch): own stores first, then the predecessors', then the file.
-struct SegHashView : HashTable {
-    HashBatch& hb;
-    const int s;                                    // index within the call
-    char tmp[13];                                   // an own store's text, copied: the log may grow under the caller
-    SegHashView(HashBatch* hb_, int s_) : hb(*hb_), s(s_) {}
-    const char* own(int slot) {
-        const auto& l = hb.log[(size_t)s];
-        for (size_t i = l.size(); i-- > 0;)
-            if (l[i].slot == slot && (l[i].kind == 1 || l[i].kind == 2)) { memcpy(tmp, l[i].call, sizeof tmp); return tmp; }
-        return nullptr;
-    }
-    const char* peek(int slot) override {
-        if (const char* c = own(slot)) return c;
-        return hb.lookup(slot, hb.seg0 + s);
-    }
-    const char* call_at(int slot) override {
-        if (const char* c = own(slot)) return c;
-        const char* c = hb.lookup(slot, hb.seg0 + s);
-        HashOp op{};
-        op.seg = hb.seg0 + s; op.slot = slot; op.kind = 3;
-        snprintf(op.call, sizeof op.call, "%s", c);
-        hb.log[(size_t)s].push_back(op);
-        return c;                                   // base / version storage: unchanged for the whole round
-    }
-    void put(int slot, const char* call, const char* grid) override {
-        HashOp op{};
-        op.seg = hb.seg0 + s; op.slot = slot; op.kind = grid ? 1 : 2;
-        snprintf(op.call, sizeof op.call, "%s", call);
-        if (grid) snprintf(op.grid, sizeof op.grid, "%s", grid);
-        hb.log[(size_t)s].push_back(op);
-    }
-};
-}  // namespace
-
 // ---------------------------------------------------------------- decoding ---
 namespace {
 
@@ -1541,44 +1418,6 @@ void Context::DecodeRun::remaining_rungs(std::vector<WaveItem>& wave) {
     }
 }
 
-// What unpacking a decoded 50-bit message and re-encoding its text yield is a pure function of the bits as long as no
-// hash look-up is involved (types 1 and 2; a type 3 asks the table): texts, the "noprint" flag, the stores into the
-// hash memory (unpk_'s and those of the re-unpack inside get_wspr_channel_symbols) and the 162 channel symbols.  A
-// receiver hears the same stations slot after slot, a batch holds thousands of copies of a few hundred messages, and
-// this host work (a dozen snprintf, the convolutional encoder, the interleaver: ~1.2 us) is most of what a rank with
-// few CPUs spends per decode.  Per host thread: the first occurrence is computed through a recording view of the
-// segment's table, later ones replay the stores into THEIR segment's table and copy the rest.
-namespace {
-struct MsgMemo {
-    struct Put { int slot; bool has_grid; char call[13]; char grid[5]; };
-    struct Entry {
-        int noprint = 0;
-        char clp[23], call[13], loc[7], pwr[3], callsign[13];
-        std::vector<Put> unpack_puts, chan_puts;
-        int chan_state = 0;                          // 0 not asked yet, 1 symbols valid, 2 the text does not encode
-        unsigned char sym[kNSymD];
-    };
-    std::unordered_map<uint64_t, Entry> map;
-};
-struct RecordingTable : HashTable {
-    HashTable& t;
-    std::vector<MsgMemo::Put>& puts;
-    bool looked_up = false;
-    RecordingTable(HashTable& t_, std::vector<MsgMemo::Put>& p) : t(t_), puts(p) {}
-    const char* call_at(int slot) override { looked_up = true; return t.call_at(slot); }
-    const char* peek(int slot) override { return t.peek(slot); }
-    void put(int slot, const char* call, const char* grid) override {
-        MsgMemo::Put p{};
-        p.slot = slot; p.has_grid = grid != nullptr;
-        snprintf(p.call, sizeof p.call, "%s", call);
-        if (grid) snprintf(p.grid, sizeof p.grid, "%s", grid);
-        puts.push_back(p);
-        t.put(slot, call, grid);
-    }
-};
-thread_local MsgMemo t_msg_memo;
-}  // namespace
-
 // Host bookkeeping in candidate order (wsprd.c:768-822).  Items of one segment are contiguous in the
 // wave and must be handled in order; different segments are independent -> one pool task per segment.
 // Returns the subtraction jobs of the wave.
@@ -1630,42 +1469,11 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         FlatHashTable flat(hashtab_of(s), loctab_of(s), &bk.dirty);
         std::unique_ptr<SegHashView> shared(hb ? new SegHashView(hb, hb_off + s) : nullptr);
         HashTable& tab = hb ? static_cast<HashTable&>(*shared) : static_cast<HashTable&>(flat);
-        // (memo: see MsgMemo above; a message that looks the table up -- type 3 -- is computed every time)
-        uint64_t mkey = 0;
-        for (int k = 0; k < 7; ++k) mkey = (mkey << 8) | w.decdata[k];
-        MsgMemo& mm = t_msg_memo;
-        if (mm.map.size() > 20000) mm.map.clear();                 // a few MB per host thread at most
-        auto mit = mm.map.find(mkey);
-        int noprint;
-        if (mit != mm.map.end()) {
-            const MsgMemo::Entry& e = mit->second;
-            noprint = e.noprint;
-            memcpy(call_loc_pow, e.clp, sizeof e.clp); memcpy(call, e.call, sizeof e.call); memcpy(loc, e.loc, sizeof e.loc);
-            memcpy(pwr, e.pwr, sizeof e.pwr); memcpy(callsign, e.callsign, sizeof e.callsign);
-            for (const MsgMemo::Put& p : e.unpack_puts) tab.put(p.slot, p.call, p.has_grid ? p.grid : nullptr);
-        } else {
-            MsgMemo::Entry e;
-            RecordingTable rec(tab, e.unpack_puts);
-            noprint = unpack_message(message, rec, call_loc_pow, call, loc, pwr, callsign);
-            if (!rec.looked_up) {
-                e.noprint = noprint;
-                memcpy(e.clp, call_loc_pow, sizeof e.clp); memcpy(e.call, call, sizeof e.call); memcpy(e.loc, loc, sizeof e.loc);
-                memcpy(e.pwr, pwr, sizeof e.pwr); memcpy(e.callsign, callsign, sizeof e.callsign);
-                mit = mm.map.emplace(mkey, std::move(e)).first;
-            }
-        }
-        auto symbols_of = [&](unsigned char* sym) -> int {          // get_wspr_channel_symbols(call_loc_pow, ...)
-            if (mit == mm.map.end()) return channel_symbols(call_loc_pow, tab, sym);
-            MsgMemo::Entry& e = mit->second;
-            if (e.chan_state == 0) {
-                RecordingTable rec(tab, e.chan_puts);
-                e.chan_state = channel_symbols(call_loc_pow, rec, e.sym) ? 1 : 2;
-            } else {
-                for (const MsgMemo::Put& p : e.chan_puts) tab.put(p.slot, p.call, p.has_grid ? p.grid : nullptr);
-            }
-            if (e.chan_state == 1) memcpy(sym, e.sym, kNSymD);
-            return e.chan_state == 1;
-        };
+        // (what the bits unpack and re-encode to is computed once per host thread: MessageCache, wspr_hashmem.h)
+        MessageCache& mc = MessageCache::of_this_thread();
+        MessageCache::Handle mh = mc.unpack(w.decdata, tab, call_loc_pow, call, loc, pwr, callsign);
+        const int noprint = mh.noprint;
+        auto symbols_of = [&](unsigned char* sym) { return mc.symbols(mh, call_loc_pow, tab, sym); };
         if (opt.subtraction && ipass == 0 && !noprint) {
             SubJob jb{};
             if (symbols_of(jb.sym)) {

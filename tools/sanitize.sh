@@ -26,8 +26,10 @@ if [ "$cmd" = build ]; then
            kernels/k7_subtract.hip host/wspr_pipeline.hip host/wspr_capi.hip; do
     $HIPCC $FLAGS $SAN -x hip -c "$src/$s" -o "$out/$(basename "${s%.*}").o" & pids+=($!)
   done
-  $CXX -O2 -gline-tables-only -std=c++17 -fPIC -ffp-contract=off -fno-omit-frame-pointer -mpopcnt -w ${SAN/-fno-gpu-sanitize/} \
-       -c "$src/host/wspr_message.cpp" -o "$out/wspr_message.o" & pids+=($!)
+  for s in wspr_message wspr_hashmem; do
+    $CXX -O2 -gline-tables-only -std=c++17 -fPIC -ffp-contract=off -fno-omit-frame-pointer -mpopcnt -w ${SAN/-fno-gpu-sanitize/} \
+         -c "$src/host/$s.cpp" -o "$out/$s.o" & pids+=($!)
+  done
   for p in "${pids[@]}"; do wait "$p"; done
   $HIPCC --offload-arch=gfx950 -shared -fPIC ${SAN/-fno-gpu-sanitize/} -shared-libsan -o "$out/libwspr_mi355x_lab.so" "$out"/*.o -lpthread
   $CXX -O1 -g -std=c++17 -fno-omit-frame-pointer ${SAN/-fno-gpu-sanitize/} -shared-libsan "$root/tools/sanitize_driver.cpp" \
