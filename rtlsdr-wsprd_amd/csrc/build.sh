@@ -14,7 +14,7 @@ inc="$here/../../include"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result ${WSPR_EXTRA_FLAGS:-}"
 srcs=(kernels/k0_decimate.hip kernels/k1_fft_bank.hip kernels/k2_k3_sync.hip kernels/k4_demod.hip
-      kernels/k6_fano_wave.hip kernels/k7_subtract.hip host/wspr_pipeline.hip host/wspr_capi.hip)
+      kernels/k6_fano_wave.hip kernels/k7_subtract.hip host/wspr_context.hip host/wspr_pipeline.hip host/wspr_capi.hip)
 
 # $1 = object directory, $2 = extra compile flags: compiles what is out of date, in parallel; object list in $objs
 compile_variant() {

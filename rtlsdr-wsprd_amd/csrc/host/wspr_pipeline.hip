@@ -11,673 +11,9 @@
 //   * the jitter ladder stops at the first Fano success -> jitter 0 is demodulated
 //     for everybody, the remaining 42 steps only for the candidates that need them.
 // The Fano decoder, message unpacking and re-encoding stay on the host (north star).
-#include "wspr_pipeline.h"
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <condition_variable>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <ctime>
-#include <functional>
-#include <mutex>
-#include <stdexcept>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "wspr_message.h"
-#include "../kernels/glibc_sincosf.h"
+#include "wspr_context_impl.h"
 
 namespace wspr {
-
-// The device's sinf / cosf restate the FMA3 build of glibc's routine, which x86-64 glibc selects on every CPU that has
-// FMA3 -- any host an MI355X sits in.  On a host whose libm is the SSE2 build the reference itself would compute 34 of
-// the 2^32 inputs differently (one ulp; all of them |x| > 17, i.e. phases of the subtraction's reference signal): the
-// host-side constant tables would follow that libm, the kernels would not.  Checked once, on six of the 34 inputs
-// (found by an exhaustive scan of both builds); a mismatch is reported loudly instead of being left to a parity test.
-static void check_host_libm_once() {
-    static const bool done = [] {
-        static const uint32_t probe[6] = {0x418a3adbu, 0x41bc76d9u, 0x4202eb4bu, 0x4255b0a9u, 0x42a35c07u, 0x42cf5854u};
-        int bad = 0;
-        for (uint32_t b : probe) {
-            float x;
-            memcpy(&x, &b, 4);
-            volatile float hx = x;                              // keep the calls out of constant folding
-            const float hs = sinf(hx), hc = cosf(hx);
-            const float ds = glibc_sinf(x), dc = glibc_cosf(x);
-            bad += (memcmp(&hs, &ds, 4) != 0) + (memcmp(&hc, &dc, 4) != 0);
-        }
-        if (bad)
-            fprintf(stderr, "libwspr_mi355x: WARNING: this host's libm computes sinf/cosf with its non-FMA build (%d of 12 probe "
-                            "values differ): the kernels reproduce the FMA build; rebuild with -DWSPR_SINCOS_FMA=0 for "
-                            "bit-exact agreement with a reference running on this host (34 of 2^32 inputs are affected)\n", bad);
-        return true;
-    }();
-    (void)done;
-}
-
-#define HIP_OK(expr)                                                                         \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) +   \
-                                     " at " #expr);                                          \
-    } while (0)
-
-// ---------------------------------------------------------------- host waits --
-// How a host thread waits for its stream.  Measured in round 5 (tools/shard_cpu_profile.py): hipEventSynchronize() --
-// on events created with hipEventBlockingSync as well -- kept the waiting thread on a CPU for the whole wait in this
-// runtime (twelve lanes in flight = twelve CPUs busy doing nothing; a rank with two CPUs was host-bound at 77 % of the
-// GPU's rate on a single-signal batch).  The default is therefore a wait that costs no CPU: poll the event for a few
-// tens of microseconds (a small batch's kernels are done by then: single-call latency is unchanged), then sleep
-// between polls, with the sleep growing to a quarter of a millisecond.  WSPR_BLOCKING_SYNC=0: the runtime's spinning
-// wait; =1: the runtime's wait on blocking events (rounds 2-4); unset or =2: poll and sleep.
-static int wait_mode() {
-    static const int m = [] { const char* e = getenv("WSPR_BLOCKING_SYNC"); return e ? atoi(e) : 2; }();
-    return m;
-}
-// how long a wait polls before it starts sleeping: a single call's kernels finish within tens to hundreds of
-// microseconds and its latency is what its caller sees (one wspr_decode() per two minutes), a large batch's take
-// milliseconds and its lanes' CPUs are what the other lanes and ranks need
-static thread_local int t_spin_us = 40;
-static void host_wait(hipEvent_t ev) {
-    if (wait_mode() != 2) {
-        const hipError_t e = hipEventSynchronize(ev);
-        if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventSynchronize");
-        return;
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    constexpr long nap_cap_ns = 250000L;        // 60 / 120 / 250 / 500 / 1000 us measured alike (profiles/r05_sleep_cap_ab.txt)
-    long nap_ns = 20000;
-    for (;;) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e == hipSuccess) return;
-        if (e != hipErrorNotReady) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventQuery");
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(t_spin_us)) { __builtin_ia32_pause(); continue; }
-        timespec ts{0, nap_ns};
-        nanosleep(&ts, nullptr);
-        nap_ns = std::min(nap_ns * 2, nap_cap_ns);
-    }
-}
-
-// ------------------------------------------------------------------ buffers --
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    void* need(size_t bytes) {
-        if (bytes > cap) {
-            if (p) HIP_OK(hipFree(p));
-            p = nullptr;
-            size_t want = bytes + bytes / 4;
-            HIP_OK(hipMalloc(&p, want));
-            cap = want;
-        }
-        return p;
-    }
-    size_t release() {
-        const size_t had = cap;
-        if (p) HIP_OK(hipFree(p));
-        p = nullptr;
-        cap = 0;
-        return had;
-    }
-    template <class T> T* as() { return static_cast<T*>(p); }
-};
-struct PinBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    void* need(size_t bytes) {
-        if (bytes > cap) {
-            if (p) HIP_OK(hipHostFree(p));
-            p = nullptr;
-            size_t want = bytes + bytes / 4;
-            HIP_OK(hipHostMalloc(&p, want, hipHostMallocDefault));
-            cap = want;
-        }
-        return p;
-    }
-    void release() {
-        if (p) HIP_OK(hipHostFree(p));
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T* as() { return static_cast<T*>(p); }
-};
-
-// ------------------------------------------------------------- thread pool --
-// Fork-join pool for the host phases between kernel launches (Fano attempts,
-// per-segment bookkeeping).  A job is an immutable heap object with two counters;
-// completion is "all tasks done", never "all workers checked in", so threads that
-// wake up late cost nothing, and a late thread holding an exhausted old job can never
-// touch a newer one.  Idle workers sleep on a condition variable; only the caller spins,
-// briefly, for the last tasks to finish.
-// worker threads of all host pools alive in this process (the calling threads of the pools are not counted)
-std::atomic<int>& pool_workers_alive() { static std::atomic<int> n{0}; return n; }
-
-class Pool {
-    struct Job {
-        const std::function<void(int)>* fn;
-        int total, chunk;
-        std::atomic<int> next{0}, done{0};
-    };
-
-public:
-    explicit Pool(int n) {
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
-        pool_workers_alive().fetch_add((int)workers_.size());
-    }
-    ~Pool() {
-        pool_workers_alive().fetch_sub((int)workers_.size());
-        quit_.store(true);
-        { std::lock_guard<std::mutex> g(m_); ++epoch_; }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    // runs fn(i) for i in [0, n); the calling thread participates.
-    // chunk = indices handed out per grab; 0 = automatic (many cheap, uniform tasks)
-    void run(int n, const std::function<void(int)>& fn, int chunk = 0) {
-        if (n <= 0) return;
-        if (workers_.empty() || n < 4) { for (int i = 0; i < n; ++i) fn(i); return; }
-        auto job = std::make_shared<Job>();
-        job->fn = &fn;
-        job->total = n;
-        job->chunk = chunk > 0 ? chunk : std::max(1, n / (8 * ((int)workers_.size() + 1)));
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = job;
-            ++epoch_;
-        }
-        cv_.notify_all();
-        drain(*job);
-        while (job->done.load(std::memory_order_acquire) < n) cpu_relax();
-    }
-    int size() const { return (int)workers_.size() + 1; }
-
-private:
-    static void cpu_relax() { __builtin_ia32_pause(); }
-    static void drain(Job& j) {
-        for (;;) {
-            const int lo = j.next.fetch_add(j.chunk);
-            if (lo >= j.total) break;
-            const int hi = std::min(j.total, lo + j.chunk);
-            for (int i = lo; i < hi; ++i) (*j.fn)(i);
-            j.done.fetch_add(hi - lo, std::memory_order_release);
-        }
-    }
-    void loop() {
-        unsigned long seen = 0;
-        for (;;) {
-            std::shared_ptr<Job> job;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (quit_.load()) return;
-                job = job_;
-            }
-            if (job) drain(*job);
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::shared_ptr<Job> job_;
-    unsigned long epoch_ = 0;
-    std::atomic<bool> quit_{false};
-};
-
-// ---------------------------------------------------------------- context ----
-namespace {
-struct SegBook {                 // host bookkeeping of one segment across passes
-    int   uniques = 0;
-    float allfreqs[100];
-    char  allcalls[100][13];
-    std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
-    std::vector<decoder_results> spots;   // every unique spot, in decode order (the reference's 100 at most)
-};
-}  // namespace
-
-struct Context::Impl {
-    hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr; // host-buffer loads, at the highest stream priority (see load_host)
-    hipEvent_t ev_copy = nullptr;
-    hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
-    int fe_cus = 0;                    // CUs the mask of fe_stream admits (0: fe_stream not in use)
-    int device = 0;
-    DeviceTables tab{};
-    DevBuf t_window, t_twiddle, t_sync, t_lpf, t_part, t_jitter, t_metric0;
-    DevBuf iqI, iqQ, ps, cand, npk, noise, smspec, seglist, items, syncbuf, symbuf, rmsbuf, jobs, subscratch,
-        nvalid, decscratch, tabs, pw, pwfreq, lists, scrsync, psavg, densein, fz_sym, fz_off, fz_ret, fz_cyc, fz_met, fz_max, fz_dat, fz_steps, fz_pool, streamraw, streamstate;
-    PinBuf h_npk, h_cand, h_items, h_sync, h_sym, h_rms, h_jobs, h_jobs2, h_seglist, h_misc, h_lists;
-    // host-buffer entry (wspr_decode_batch: the reference's calling convention, wsprd.h:106-111): pageable caller rows
-    // are gathered into two pinned chunks in the working layout (rows of kIqStride floats, zero tail) that take turns,
-    // so that the host's gather of chunk k+1 runs under the DMA of chunk k and every DMA is one contiguous copy
-    PinBuf h_fz;                     // K6w's results on their way to the host (a copy into pageable memory would make
-                                     // the runtime wait for the search itself, on a CPU)
-    PinBuf h_stage[2];
-    hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    int stage_samples[2] = {0, 0};   // columns [samples, kIqStride) of a chunk are zero from here on
-    int sub_flip = 0;
-    bool dev_fano = false;           // this batch: Fano attempts on the device (see fano_device_mode())
-    bool crowded = false;            // the previous batch had more than one Fano time-out per ten segments
-    int cand_head = 16;              // candidates per segment copied to the host (adapts to the lists seen)
-    // host mirrors that keep their storage between calls: value-initialising 8 192 x 200 candidate slots (46 MB) and
-    // 8 192 segment books (14 MB) per call was a fifth of the host's CPU time per step on a single-signal batch
-    std::vector<DevCand> cand_host;
-    std::vector<int> npk_host;
-    std::vector<SegBook> books;
-    std::unique_ptr<Pool> pool;      // <= 32 threads: the short phases (first-rung Fano, bookkeeping)
-    std::unique_ptr<Pool> bigpool;   // every host thread we may use: the long Fano ladders of weak candidates
-    int jitter_ladder[kMaxLags];
-    // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
-    char* hash_arena = nullptr;
-    size_t hash_arena_segs = 0;
-    double t_ms[24] = {0};           // stage times (ms), Fano statistics and host CPU time by phase of the last batch
-    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0};
-    bool blocking = false;
-    hipEvent_t ev_sync = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    // spans timed without a host wait: event pairs recorded around the launches, read back after a later
-    // synchronisation of the same (in-order) stream has passed them
-    static constexpr int kDeferred = 8;
-    hipEvent_t ev_def[kDeferred][2] = {};
-    double* def_acc[kDeferred] = {};
-    int n_def = 0;
-    void resolve_deferred() {
-        for (int i = 0; i < n_def; ++i) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, ev_def[i][0], ev_def[i][1]) == hipSuccess) *def_acc[i] += ms;
-        }
-        n_def = 0;
-    }
-};
-
-// CPUs this process may actually use: hardware threads capped by the cgroup CPU quota
-// (a container on a shared GPU node typically owns a slice; running more runnable threads
-// than the quota gets the whole process throttled)
-static int usable_cpus();
-// CPUs this process may count on: WSPR_HOST_THREADS (a rank's share when several ranks share a host),
-// else the cgroup quota / affinity mask
-static int host_cpus() {
-    static const int n = [] {
-        int v = usable_cpus();
-        if (const char* e = getenv("WSPR_HOST_THREADS")) v = atoi(e);
-        return std::max(1, v);
-    }();
-    return n;
-}
-// Shards of one node-level call that share this host's CPUs (wspr_decode_batch_node: one per device): contexts
-// created from then on size their pools for a 1/n share, as a rank of an N-rank job does via WSPR_HOST_THREADS.
-std::atomic<int>& node_share() {
-    static std::atomic<int> v{1};
-    return v;
-}
-static int rank_cpus() { return std::max(1, host_cpus() / std::max(1, node_share().load())); }
-static int usable_cpus() {
-    int n = (int)std::thread::hardware_concurrency();
-    if (n <= 0) n = 1;
-    long quota = -1, period = -1;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2
-        char q[32] = {0};
-        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
-        fclose(f);
-    } else {
-        if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f1, "%ld", &quota) != 1) quota = -1; fclose(f1); }
-        if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%ld", &period) != 1) period = -1; fclose(f2); }
-    }
-    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1L, (quota + period - 1) / period));
-    return n;
-}
-
-static void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
-    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
-}
-
-Context::Context(int nslots) : d(new Impl) {
-    check_host_libm_once();
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
-    HIP_OK(hipGetDevice(&d->device));
-    HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    // Waiting host threads sleep on blocking events instead of spinning: never slower here (184 k vs
-    // 180 k segments/s with 16 CPUs, 129 k vs 123 k with 2) and it leaves the CPUs to the Fano pools and
-    // to other ranks.  WSPR_BLOCKING_SYNC=0 restores spinning.
-    d->blocking = wait_mode() != 0;
-    const unsigned evflags = wait_mode() == 1 ? hipEventBlockingSync : hipEventDefault;
-    HIP_OK(hipEventCreateWithFlags(&d->ev[0], evflags));
-    HIP_OK(hipEventCreateWithFlags(&d->ev[1], evflags));
-    HIP_OK(hipEventCreateWithFlags(&d->ev_sync, evflags | hipEventDisableTiming));
-    for (auto& pr : d->ev_def) { HIP_OK(hipEventCreate(&pr[0])); HIP_OK(hipEventCreate(&pr[1])); }
-    for (auto& e : d->ev_stage) HIP_OK(hipEventCreateWithFlags(&e, evflags | hipEventDisableTiming));
-    {
-        int least = 0, greatest = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_OK(hipStreamCreateWithPriority(&d->copy_stream, hipStreamNonBlocking, greatest));
-        HIP_OK(hipEventCreateWithFlags(&d->ev_copy, hipEventDisableTiming));
-    }
-
-    // constant tables, computed with the host libm exactly as the reference does
-    std::vector<float> window(kFftSize), lpf(kLpfTaps), part(kLpfTaps);
-    for (int j = 0; j < kFftSize; ++j) window[j] = sinf(0.006147931 * j);          // wsprd.c:509-513
-    std::vector<float2> tw(256);
-    for (int k = 0; k < 256; ++k) {
-        const double a = 2.0 * M_PI * (double)k / 512.0;
-        tw[k] = make_float2((float)cos(a), (float)(-sin(a)));
-    }
-    tw[0] = make_float2(1.0f, 0.0f);
-    tw[128] = make_float2(0.0f, -1.0f);
-    float norm = 0.0f;                                                               // wsprd.c:353-368
-    for (int i = 0; i < kLpfTaps; ++i) { lpf[i] = sinf(M_PI * (float)i / (float)(kLpfTaps - 1)); norm = norm + lpf[i]; }
-    for (int i = 0; i < kLpfTaps; ++i) lpf[i] = lpf[i] / norm;
-    part[0] = 0.0f;
-    for (int i = 1; i < kLpfTaps; ++i) part[i] = part[i - 1] + lpf[i];
-    for (int idt = 0; idt < kMaxLags; ++idt) {                                       // wsprd.c:742-744
-        int ii = (idt + 1) / 2;
-        if (idt % 2 == 1) ii = -ii;
-        d->jitter_ladder[idt] = 3 * ii;
-    }
-    upload(d->t_window.need(window.size() * 4), window.data(), window.size() * 4, d->stream);
-    upload(d->t_twiddle.need(tw.size() * 8), tw.data(), tw.size() * 8, d->stream);
-    upload(d->t_sync.need(kNSym), sync_vector(), kNSym, d->stream);
-    upload(d->t_lpf.need(lpf.size() * 4), lpf.data(), lpf.size() * 4, d->stream);
-    upload(d->t_part.need(part.size() * 4), part.data(), part.size() * 4, d->stream);
-    upload(d->t_jitter.need(sizeof d->jitter_ladder), d->jitter_ladder, sizeof d->jitter_ladder, d->stream);
-    {
-        static short metric0[256];
-        for (int i = 0; i < 256; ++i) metric0[i] = (short)default_metrics().tab[0][i];
-        upload(d->t_metric0.need(sizeof metric0), metric0, sizeof metric0, d->stream);
-    }
-    HIP_OK(hipStreamSynchronize(d->stream));
-    d->tab.window = d->t_window.as<float>();
-    d->tab.twiddle = d->t_twiddle.as<float2>();
-    d->tab.sync = d->t_sync.as<unsigned char>();
-    d->tab.lpf = d->t_lpf.as<float>();
-    d->tab.lpf_part = d->t_part.as<float>();
-    d->tab.min_snr = powf(10.0, -8.0 / 10.0);                                        // wsprd.c:590
-    d->tab.floor_snr = 0.1 * d->tab.min_snr;                                         // wsprd.c:595
-
-    int nthreads = rank_cpus();
-    nthreads = std::max(1, std::min(nthreads, 256) / std::max(1, nslots));   // the slots share the host's CPUs
-    d->pool.reset(new Pool(std::min(nthreads, 16) - 1));   // short phases: more threads only add wake-up cost
-    d->bigpool.reset(new Pool(nthreads - 1));
-}
-
-Context::~Context() {}
-
-// Number of concurrent pipelines ("slots"): each owns a HIP stream, buffers and host pools and
-// decodes its own share of a batch, so that one slot's host phases (Fano, bookkeeping, copies)
-// overlap the other slots' kernels.
-// Three slots need about three CPUs for their driver threads (kernel launches are the host's main
-// cost); with fewer, extra slots only take each other's time slices (2 CPUs: 2 slots 155 k, 3 slots
-// 128 k segments/s on config 2).
-int Context::slots() {
-    static const int n = [] {
-        int v = std::min(3, host_cpus());
-        if (const char* e = getenv("WSPR_SLOTS")) v = atoi(e);
-        return std::max(1, std::min(v, 8));
-    }();
-    return n;
-}
-
-// Lanes: independent sets of slot contexts.  A host thread is bound to one lane (default 0); calls
-// made from threads bound to different lanes share nothing but the device and may overlap, which
-// lets a service pipeline batch k+1 under the tail of batch k.
-static thread_local int t_lane = 0;
-static thread_local int t_slot_cap = 8;
-int Context::lane() { return t_lane; }
-void Context::cap_slots(int n) { t_slot_cap = std::max(1, n); }
-int Context::slot_cap() { return std::min(slots(), std::min(t_slot_cap, rank_cpus())); }
-void Context::bind_lane(int lane) { t_lane = std::max(0, std::min(lane, kMaxLanes - 1)); }
-
-// Contexts are kept per (device, lane, slot): a host thread decodes on the HIP device that is current for it
-// (hipSetDevice / wspr_set_device), so one process can drive every GPU of a node, one thread (or more) each.
-static std::mutex g_ctx_mutex;
-static std::unique_ptr<Context> g_ctx[Context::kMaxDevices][Context::kMaxLanes][8];
-
-Context& Context::slot(int i) {
-    std::mutex& m = g_ctx_mutex;
-    auto& ctx = g_ctx;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess)
-        throw std::runtime_error("libwspr_mi355x: no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
-    if (dev < 0 || dev >= kMaxDevices) throw std::runtime_error("libwspr_mi355x: device index out of range");
-    std::lock_guard<std::mutex> g(m);
-    std::unique_ptr<Context>& p = ctx[dev][t_lane][i];
-    if (!p) p.reset(new Context(slots()));
-    return *p;
-}
-
-Context& Context::get() { return slot(0); }
-
-Context* Context::slot_if_exists(int i) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || i < 0 || i >= 8) return nullptr;
-    std::lock_guard<std::mutex> g(g_ctx_mutex);
-    return g_ctx[dev][t_lane][i].get();
-}
-static thread_local int t_slots_used = 1;
-void Context::note_slots_used(int n) { t_slots_used = std::max(1, n); }
-int Context::last_slots_used() { return t_slots_used; }
-
-// Work buffers (device and pinned) of every context of the current device go back to the driver; the constant
-// tables, streams and host pools stay, the next call allocates what it needs.  No call may be in flight.
-size_t Context::release_buffers() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
-    std::lock_guard<std::mutex> g(g_ctx_mutex);
-    size_t freed = 0;
-    for (int lane = 0; lane < kMaxLanes; ++lane)
-        for (int i = 0; i < 8; ++i) {
-            if (!g_ctx[dev][lane][i]) continue;
-            Impl& c = *g_ctx[dev][lane][i]->d;
-            HIP_OK(hipStreamSynchronize(c.stream));
-            if (c.fe_stream) HIP_OK(hipStreamSynchronize(c.fe_stream));
-            for (DevBuf* b : {&c.iqI, &c.iqQ, &c.ps, &c.cand, &c.npk, &c.noise, &c.smspec, &c.seglist, &c.items, &c.syncbuf,
-                              &c.symbuf, &c.rmsbuf, &c.jobs, &c.subscratch, &c.nvalid, &c.decscratch, &c.tabs, &c.pw, &c.pwfreq,
-                              &c.lists, &c.scrsync, &c.psavg, &c.densein, &c.fz_sym, &c.fz_off, &c.fz_ret, &c.fz_cyc, &c.fz_met, &c.fz_max,
-                              &c.fz_dat, &c.fz_steps, &c.fz_pool, &c.streamraw, &c.streamstate})
-                freed += b->release();
-            for (PinBuf* b : {&c.h_npk, &c.h_cand, &c.h_items, &c.h_sync, &c.h_sym, &c.h_rms, &c.h_jobs, &c.h_jobs2, &c.h_seglist,
-                              &c.h_misc, &c.h_lists, &c.h_fz, &c.h_stage[0], &c.h_stage[1]})
-                b->release();
-            c.stage_samples[0] = c.stage_samples[1] = 0;
-            free(c.hash_arena);
-            c.hash_arena = nullptr;
-            c.hash_arena_segs = 0;
-        }
-    return freed;
-}
-
-int Context::device() { return d->device; }
-
-hipStream_t Context::stream() { return d->stream; }
-const DeviceTables& Context::tables() { return d->tab; }
-int Context::host_threads() { return d->bigpool->size(); }
-
-float* Context::work_i(int nseg) { return static_cast<float*>(d->iqI.need((size_t)nseg * kIqStride * 4)); }
-float* Context::work_q(int nseg) { return static_cast<float*>(d->iqQ.need((size_t)nseg * kIqStride * 4)); }
-
-// rows are kIqStride floats; everything past `samples` must read as zero (the FFT bank
-// of the reference reads up to 512*floor(samples/512)+255, wsprd.c:536-542)
-static void zero_tail(float* wi, float* wq, int nseg, int samples, hipStream_t st) {
-    const size_t tail = (size_t)(kIqStride - samples) * 4;
-    HIP_OK(hipMemset2DAsync(wi + samples, (size_t)kIqStride * 4, 0, tail, nseg, st));
-    HIP_OK(hipMemset2DAsync(wq + samples, (size_t)kIqStride * 4, 0, tail, nseg, st));
-}
-
-// Is this host address pinned (hipHostMalloc / hipHostRegister / wspr_pin_host_buffer)?  Pageable memory is "not
-// registered" (an error on older runtimes: cleared).
-static bool host_is_pinned(const void* p) {
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
-
-// One turnstile per device for the host-buffer loads: calls in flight on several lanes (and the slots of one call) take
-// the PCIe link one after the other instead of sharing it, so the first of them has its data -- and starts computing
-// under the others' transfers -- after 1/n of the time.
-static std::mutex& host_load_turn(int device) {
-    static std::mutex m[Context::kMaxDevices];
-    return m[std::max(0, std::min(device, Context::kMaxDevices - 1))];
-}
-
-// The gathers of pageable rows are memcpy-bound (about 9 GB/s per thread here): one pool per process for them, half
-// the CPUs of the rank's share but at most eight threads, used by one gather at a time.
-static Pool& gather_pool(std::unique_lock<std::mutex>& hold) {
-    static std::mutex m;
-    static Pool pool(std::max(1, std::min(8, rank_cpus() / 2)) - 1);
-    hold = std::unique_lock<std::mutex>(m);
-    return pool;
-}
-
-// The reference's callers hand wspr_decode() HOST buffers (rtlsdr_wsprd.c:316, :689).  Pinned caller memory goes to
-// the device as one asynchronous strided copy per rail (DMA at the link's rate, no host work).  Pageable caller memory
-// would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows are gathered
-// (host pool) into this context's two pinned chunks, already in the working layout, and each chunk leaves as ONE
-// contiguous asynchronous copy per rail while the pool fills the other chunk.
-void Context::load_host(const float* I, const float* Q, int nseg, int samples, size_t stride) {
-    Impl& c = *d;
-    float* wi = work_i(nseg);
-    float* wq = work_q(nseg);
-    if (nseg <= 0) return;
-    // The transfers run on a stream of the HIGHEST priority and the decode stream waits for its last event.  Measured
-    // (tools/dma_interference.py): beside twelve lanes of decoder kernels a linear pinned-to-device copy on an ordinary
-    // stream gets 10-18 GB/s of the link's 55 -- its queue's packets wait their turn behind kernels -- and 35 GB/s on a
-    // high-priority stream, with the decoder's step unchanged either way (the DMA engines do the work).
-    const hipStream_t ld = c.copy_stream;
-    struct Join {                                                    // whatever path is taken: the decode stream follows the load
-        Impl& c;
-        ~Join() {
-            (void)hipEventRecord(c.ev_copy, c.copy_stream);
-            (void)hipStreamWaitEvent(c.stream, c.ev_copy, 0);
-        }
-    } join{c};
-    // One load at a time per device (the turnstile): the lane whose turn it is has the link to itself and its batch in
-    // HBM after 1/n of the time n concurrent loads would take -- and starts computing under the next lane's transfer.
-    std::unique_lock<std::mutex> turn(host_load_turn(c.device), std::defer_lock);
-    auto finish_turn = [&] {                                     // the turn ends when the LINK is free again, not when
-        HIP_OK(hipEventRecord(c.ev_copy, ld));                   // the copies have merely been queued
-        host_wait(c.ev_copy);
-    };
-    if (host_is_pinned(I) && host_is_pinned(Q)) {
-        turn.lock();
-        // Pinned rows: LINEAR copies (the DMA engines at the link's rate, no CU involved) of up to kDense rows at a time
-        // into a dense device buffer, and the row kernel that also serves resident input spreads them into the working
-        // layout (device to device, microseconds).  A strided host-to-device copy straight into the working rows measured
-        // 40-45 GB/s against 55 for the linear one (round 5).
-        // (rows far apart -- a stride of more than twice the record -- would make a linear copy carry the gaps: those
-        // take the strided copy below)
-        if ((samples & 3) == 0 && (stride & 3) == 0 && stride <= 2 * (size_t)samples &&
-            !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
-            constexpr int kDense = 256;
-            const int per = std::min(nseg, kDense);
-            // two dense buffers in turn: the row kernel of chunk k runs under the DMA of chunk k + 1
-            float* dn0 = static_cast<float*>(c.densein.need((size_t)4 * per * stride * 4));
-            for (int c0 = 0, k = 0; c0 < nseg; c0 += per, ++k) {
-                const int n = std::min(per, nseg - c0);
-                float* dn = dn0 + (size_t)(k & 1) * 2 * per * stride;
-                const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
-                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
-                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
-                if (!launch_load_rows(dn, dn + (size_t)per * stride, stride, samples, n, wi + (size_t)c0 * kIqStride,
-                                      wq + (size_t)c0 * kIqStride, ld))
-                    throw std::runtime_error("load_rows refused an aligned dense chunk");
-            }
-        } else {
-            zero_tail(wi, wq, nseg, samples, ld);
-            HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-            HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-        }
-        if (nseg >= 16) finish_turn();
-        return;
-    }
-    if (nseg < 16) {                                             // a single call's record or a handful: the runtime's own path
-        zero_tail(wi, wq, nseg, samples, ld);
-        HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-        HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-        return;
-    }
-    // Pageable rows: gathered by the host pool into this context's two pinned chunks, already in the working layout
-    // (rows of kIqStride floats, zero tail), each chunk then ONE linear copy per rail.  The first two chunks are gathered
-    // BEFORE the turn is taken (the link belongs to another lane meanwhile), the others under the DMA of their
-    // predecessors.
-    constexpr int chunk = 64;                                    // segments per chunk: 11.5 MB per rail, two rails, two chunks
-    const size_t row = (size_t)kIqStride, rail = (size_t)chunk * row;      // floats; the layout of a chunk never changes
-    auto gather = [&](int k) {
-        const int c0 = k * chunk, n = std::min(chunk, nseg - c0), b = k & 1;
-        const bool fresh = c.h_stage[b].cap < 2 * rail * 4;
-        float* st = static_cast<float*>(c.h_stage[b].need(2 * rail * 4));
-        if (fresh) { memset(st, 0, 2 * rail * 4); c.stage_samples[b] = 0; }
-        else if (k >= 2) host_wait(c.ev_stage[b]);                           // the DMA that read this chunk two turns ago
-        const int dirty = c.stage_samples[b];                    // a shorter record than the last one leaves old samples behind
-        auto fill = [&](int r) {
-            float* di = st + (size_t)r * row;
-            float* dq = st + rail + (size_t)r * row;
-            memcpy(di, I + (size_t)(c0 + r) * stride, (size_t)samples * 4);
-            memcpy(dq, Q + (size_t)(c0 + r) * stride, (size_t)samples * 4);
-            if (dirty > samples) {
-                memset(di + samples, 0, (size_t)(dirty - samples) * 4);
-                memset(dq + samples, 0, (size_t)(dirty - samples) * 4);
-            }
-        };
-        if (n >= 8) {
-            std::unique_lock<std::mutex> hold;
-            gather_pool(hold).run(n, fill, 2);
-        } else {
-            for (int r = 0; r < n; ++r) fill(r);
-        }
-        // every row of the chunk now ends at `samples` (rows beyond n: whatever they held, never sent)
-        c.stage_samples[b] = (n == chunk) ? samples : std::max(dirty, samples);
-    };
-    auto send = [&](int k) {
-        const int c0 = k * chunk, n = std::min(chunk, nseg - c0), b = k & 1;
-        const float* st = c.h_stage[b].as<float>();
-        HIP_OK(hipMemcpyAsync(wi + (size_t)c0 * row, st, (size_t)n * row * 4, hipMemcpyHostToDevice, ld));
-        HIP_OK(hipMemcpyAsync(wq + (size_t)c0 * row, st + rail, (size_t)n * row * 4, hipMemcpyHostToDevice, ld));
-        HIP_OK(hipEventRecord(c.ev_stage[b], ld));
-    };
-    const int nchunks = (nseg + chunk - 1) / chunk;
-    gather(0);
-    if (nchunks > 1) gather(1);
-    turn.lock();
-    send(0);
-    if (nchunks > 1) send(1);
-    for (int k = 2; k < nchunks; ++k) { gather(k); send(k); }
-    finish_turn();
-    // the caller's rows were consumed by the gathers and may change from here on
-}
-void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {
-    float* wi = work_i(nseg);
-    float* wq = work_q(nseg);
-    if (launch_load_rows(static_cast<const float*>(dI), static_cast<const float*>(dQ), stride, samples, nseg, wi, wq, d->stream))
-        return;
-    zero_tail(wi, wq, nseg, samples, d->stream);
-    HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, dI, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));
-    HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, dQ, stride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToDevice, d->stream));
-}
-void Context::store_host(float* I, float* Q, int nseg, int samples, size_t stride) {
-    HIP_OK(hipMemcpy2DAsync(I, stride * 4, d->iqI.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
-    HIP_OK(hipMemcpy2DAsync(Q, stride * 4, d->iqQ.p, (size_t)kIqStride * 4, (size_t)samples * 4, nseg, hipMemcpyDeviceToHost, d->stream));
-    sync();
-}
-void Context::sync() {
-    HIP_OK(hipGetLastError());
-    if (d->blocking) {
-        HIP_OK(hipEventRecord(d->ev_sync, d->stream));
-        host_wait(d->ev_sync);
-    } else {
-        HIP_OK(hipStreamSynchronize(d->stream));
-    }
-    d->resolve_deferred();
-}
-
-float* Context::ps_buffer(int nseg) {
-    return static_cast<float*>(d->ps.need((size_t)nseg * kPsBins * kPsTPitch * 4));
-}
 
 // ---------------------------------------------------------------- stages -----
 // K1 + K2a over `nactive` segments; ev (optional): an event before and after each kernel.
@@ -1882,163 +1218,6 @@ int Context::fano_resident(const unsigned char* d_symbols, const int* h_offsets,
         ret[i] = fano_decode(&metric, &cycles[i], &maxnp, out11, sym, kNBits, met.tab, 60, maxcycles);
         memcpy(data + (size_t)i * 10, out11, 10);
     }
-    return 0;
-}
-
-// restore the original IQ of single segments (rows) of the working buffers
-void Context::reload_rows(const float* I, const float* Q, bool device, size_t stride, int samples,
-                          const std::vector<int>& segs) {
-    Impl& c = *d;
-    const hipMemcpyKind kind = device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int s : segs) {
-        HIP_OK(hipMemcpyAsync(c.iqI.as<float>() + (size_t)s * kIqStride, I + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));
-        HIP_OK(hipMemcpyAsync(c.iqQ.as<float>() + (size_t)s * kIqStride, Q + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));
-    }
-    if (!device) sync();       // pageable host memory: the copies must not outlive the caller's view
-}
-
-// ------------------------------------------------------- single-call stages --
-void Context::demod_single(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin,
-                           int ifmax, float fstep, int* shift, int lagmin, int lagmax, int lagstep,
-                           float* drift, float* sync, int mode, int symfac) {
-    Impl& c = *d;
-    const int samples = (int)std::min<long>(np, kMaxSamples);
-    load_host(id, qd, 1, samples, (size_t)samples);
-    FineState f{};
-    f.seg = 0; f.freq = *freq; f.drift = *drift; f.shift = *shift; f.sync = 1e30f;
-    f.freq_coarse = *freq; f.shift_coarse = lagmin + 128;
-    FineState* d_items = static_cast<FineState*>(c.items.need(sizeof(FineState)));
-    upload(d_items, &f, sizeof f, c.stream);
-    const float* wi = c.iqI.as<float>();
-    const float* wq = c.iqQ.as<float>();
-    if (mode == 0) {
-        const int nl = (lagmax - lagmin) / lagstep + 1;
-        float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nl * 4));
-        launch_demod(wi, wq, (int)np, d_items, 1, 0, nl, lagstep, 0, 0.0f, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
-        launch_pick_lag(d_items, 1, d_sync, nl, lagstep, c.stream);
-    } else if (mode == 1) {
-        const int nf = ifmax - ifmin + 1;
-        float* d_sync = static_cast<float*>(c.syncbuf.need((size_t)nf * 4));
-        launch_demod(wi, wq, (int)np, d_items, 1, 1, nf, lagstep, ifmin, fstep, nullptr, 0.0f, d_sync, nullptr, nullptr, c.tab, c.stream);
-        launch_pick_freq(d_items, 1, d_sync, nf, ifmin, fstep, c.stream);
-    } else {
-        float* d_sync = static_cast<float*>(c.syncbuf.need(4));
-        unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need(kNSymD));
-        float* d_rms = static_cast<float*>(c.rmsbuf.need(4));
-        launch_demod(wi, wq, (int)np, d_items, 1, 2, 1, lagstep, 0, 0.0f, c.t_jitter.as<int>(), -INFINITY, d_sync, d_sym, d_rms, c.tab, c.stream, symfac);
-        float s2 = 0;
-        HIP_OK(hipMemcpyAsync(&s2, d_sync, 4, hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipMemcpyAsync(symbols, d_sym, kNSymD, hipMemcpyDeviceToHost, c.stream));
-        HIP_OK(hipStreamSynchronize(c.stream));
-        *sync = s2;
-        return;
-    }
-    HIP_OK(hipMemcpyAsync(&f, d_items, sizeof f, hipMemcpyDeviceToHost, c.stream));
-    HIP_OK(hipStreamSynchronize(c.stream));
-    *sync = f.sync; *shift = f.shift; *freq = f.freq;
-}
-
-void Context::subtract_single(float* id, float* qd, long np, float f0, int shift, float drift,
-                              const unsigned char* sym) {
-    Impl& c = *d;
-    const int samples = (int)std::min<long>(np, kMaxSamples);
-    load_host(id, qd, 1, samples, (size_t)samples);
-    SubJob jb{};
-    jb.seg = 0; jb.f0 = f0; jb.shift = shift; jb.drift = drift;
-    memcpy(jb.sym, sym, kNSymD);
-    SubJob* dj = static_cast<SubJob*>(c.jobs.need(sizeof jb));
-    upload(dj, &jb, sizeof jb, c.stream);
-    float* scratch = static_cast<float*>(c.subscratch.need(subtract_scratch_floats(1) * 4));
-    launch_subtract(c.iqI.as<float>(), c.iqQ.as<float>(), (int)np, dj, 1, scratch, c.tab, c.stream);
-    store_host(id, qd, 1, samples, (size_t)samples);
-}
-
-void Context::subtract_symbolwise_single(float* id, float* qd, long np, float f0, int shift, float drift,
-                                         const unsigned char* sym) {
-    Impl& c = *d;
-    const int samples = (int)std::min<long>(np, kMaxSamples);
-    load_host(id, qd, 1, samples, (size_t)samples);
-    unsigned char* d_sym = static_cast<unsigned char*>(c.symbuf.need(kNSymD));
-    upload(d_sym, sym, kNSymD, c.stream);
-    launch_subtract_symbolwise(c.iqI.as<float>(), c.iqQ.as<float>(), samples, f0, shift, drift, d_sym, c.stream);
-    store_host(id, qd, 1, samples, (size_t)samples);
-}
-
-// CUs the front end may occupy (0 = all).  K0 is HBM-bound and launches hundreds of thousands of short workgroups:
-// on an unmasked stream they take every CU as it frees up and the decoder's fp32-bound kernels of the other lanes
-// wait.  Confined to a share of the CUs (a stream created with hipExtStreamCreateWithCUMask; consecutive mask bits
-// fall on different XCDs, so the share is spread over all eight and keeps every HBM stack busy), K0 still finds
-// the memory bandwidth it needs while the rest of the chip keeps computing.
-std::atomic<int>& front_end_cus() {
-    static std::atomic<int> v{[] { const char* e = lab_env("WSPR_K0_CUS"); return e ? atoi(e) : 0; }()};
-    return v;
-}
-
-hipStream_t Context::front_end_stream() {
-    Impl& c = *d;
-    const int want = front_end_cus().load();
-    if (want != c.fe_cus) {
-        if (c.fe_stream) { (void)hipStreamSynchronize(c.fe_stream); (void)hipStreamDestroy(c.fe_stream); c.fe_stream = nullptr; }
-        c.fe_cus = want;
-        if (want > 0) {
-            hipDeviceProp_t prop;
-            HIP_OK(hipGetDeviceProperties(&prop, c.device));
-            const int ncu = prop.multiProcessorCount;
-            const int n = std::max(8, std::min(want, ncu));
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int i = 0; i < n; ++i) mask[i >> 5] |= 1u << (i & 31);
-            HIP_OK(hipExtStreamCreateWithCUMask(&c.fe_stream, (uint32_t)mask.size(), mask.data()));
-        }
-    }
-    return c.fe_stream ? c.fe_stream : c.stream;
-}
-
-int Context::decimate_device(const void* d_raw, size_t bytes_per_seg, int nseg, float* dI, float* dQ, int normalise,
-                             int* h_nout, DecimState* d_states) {
-    Impl& c = *d;
-    const hipStream_t st = d_states ? c.stream : front_end_stream();     // whole segments only: streaming chunks are small
-    const size_t nblocks = (size_t)decimate_blocks(bytes_per_seg / 2, d_states != nullptr);
-    if (nblocks == 0) return -1;
-    int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)nseg * nblocks * 24));
-    int* d_nv = static_cast<int*>(c.nvalid.need((size_t)nseg * 4));
-    if (!d_states) {                                          // whole segments: the unfilled tail must read as zero
-        HIP_OK(hipMemsetAsync(dI, 0, (size_t)nseg * kIqStride * 4, st));
-        HIP_OK(hipMemsetAsync(dQ, 0, (size_t)nseg * kIqStride * 4, st));
-    }
-    launch_decimate(static_cast<const uint8_t*>(d_raw), bytes_per_seg, nseg, dI, dQ, d_nv, scratch, st, d_states);
-    if (normalise) launch_normalise(dI, dQ, d_nv, nseg, kMaxSamples, st);
-    if (h_nout) HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
-    if (c.blocking) {
-        HIP_OK(hipEventRecord(c.ev_sync, st));
-        host_wait(c.ev_sync);
-    } else {
-        HIP_OK(hipStreamSynchronize(st));
-    }
-    return 0;
-}
-
-// one chunk of one receiver's stream: state in, appended outputs and state out (host buffers)
-int Context::decimate_stream(DecimState* h_state, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
-                             uint32_t cap, uint32_t* new_fill) {
-    Impl& c = *d;
-    if (nbytes == 0) { if (new_fill) *new_fill = fill; return 0; }
-    uint8_t* d_raw = static_cast<uint8_t*>(c.streamraw.need(nbytes + 16));
-    DecimState* d_st = static_cast<DecimState*>(c.streamstate.need(sizeof(DecimState)));
-    upload(d_raw, iq, nbytes, c.stream);
-    upload(d_st, h_state, sizeof(DecimState), c.stream);
-    float* wi = work_i(1);
-    float* wq = work_q(1);
-    int nout = 0;
-    const int rc = decimate_device(d_raw, nbytes, 1, wi, wq, 0, &nout, d_st);
-    if (rc) return rc;
-    HIP_OK(hipMemcpy(h_state, d_st, sizeof(DecimState), hipMemcpyDeviceToHost));
-    const uint32_t room = fill < cap ? cap - fill : 0u;
-    const uint32_t take = std::min<uint32_t>((uint32_t)nout, room);       // outputs beyond the capacity are dropped
-    if (take) {                                                            // (rtlsdr_wsprd.c:236-242)
-        HIP_OK(hipMemcpy(I + fill, wi, (size_t)take * 4, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(Q + fill, wq, (size_t)take * 4, hipMemcpyDeviceToHost));
-    }
-    if (new_fill) *new_fill = fill + take;
     return 0;
 }
 

@@ -23,7 +23,7 @@ if [ "$cmd" = build ]; then
   src="$root/rtlsdr-wsprd_amd/csrc"
   pids=()
   for s in kernels/k0_decimate.hip kernels/k1_fft_bank.hip kernels/k2_k3_sync.hip kernels/k4_demod.hip kernels/k6_fano_wave.hip \
-           kernels/k7_subtract.hip host/wspr_pipeline.hip host/wspr_capi.hip; do
+           kernels/k7_subtract.hip host/wspr_context.hip host/wspr_pipeline.hip host/wspr_capi.hip; do
     $HIPCC $FLAGS $SAN -x hip -c "$src/$s" -o "$out/$(basename "${s%.*}").o" & pids+=($!)
   done
   for s in wspr_message wspr_hashmem; do
