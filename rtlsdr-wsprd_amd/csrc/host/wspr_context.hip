@@ -239,6 +239,20 @@ static Pool& gather_pool(std::unique_lock<std::mutex>& hold) {
     return pool;
 }
 
+// A row into a pinned chunk with streaming stores: the chunk is written once and read by the DMA engine, never by this
+// CPU again, so it need not pass through (and evict from) the caches, and a line need not be read before it is written.
+// dst is 32-byte aligned (rows of kIqStride floats in a page-aligned chunk), src is wherever the caller's row starts.
+static inline void copy_row_streaming(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    typedef float v8u __attribute__((vector_size(32), aligned(4)));
+    typedef float v8 __attribute__((vector_size(32)));
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const v8u x = *reinterpret_cast<const v8u*>(src + i);
+        __builtin_nontemporal_store(static_cast<v8>(x), reinterpret_cast<v8*>(dst + i));
+    }
+    for (; i < n; ++i) dst[i] = src[i];
+}
+
 // The reference's callers hand wspr_decode() HOST buffers (rtlsdr_wsprd.c:316, :689).  Pinned caller memory goes to
 // the device as one asynchronous strided copy per rail (DMA at the link's rate, no host work).  Pageable caller memory
 // would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows are gathered
@@ -322,12 +336,13 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
         auto fill = [&](int r) {
             float* di = st + (size_t)r * row;
             float* dq = st + rail + (size_t)r * row;
-            memcpy(di, I + (size_t)(c0 + r) * stride, (size_t)samples * 4);
-            memcpy(dq, Q + (size_t)(c0 + r) * stride, (size_t)samples * 4);
+            copy_row_streaming(di, I + (size_t)(c0 + r) * stride, (size_t)samples);
+            copy_row_streaming(dq, Q + (size_t)(c0 + r) * stride, (size_t)samples);
             if (dirty > samples) {
                 memset(di + samples, 0, (size_t)(dirty - samples) * 4);
                 memset(dq + samples, 0, (size_t)(dirty - samples) * 4);
             }
+            __builtin_ia32_sfence();                              // the streaming stores are visible before the DMA is queued
         };
         if (n >= 8) {
             std::unique_lock<std::mutex> hold;
