@@ -252,7 +252,7 @@ def k0_report(L, m, with_cpu=True):
     k0_bytes = (RAW_BYTES + 360000) * nraw
     rms = (C.c_double * 1)()
     L.wspr_calib_read(raw.data_ptr(), RAW_BYTES, nraw, 10, C.addressof(rms))
-    out = {"bound": "hbm", "kernel": "cic_block_sums_fast_kernel + cic_comb_fir_kernel + normalise_kernel",
+    out = {"bound": "hbm", "kernel": "cic_block_sums_mfma_kernel + cic_comb_fir_kernel + normalise_kernel",
            "segments_per_launch": nraw, "avg_launch_ms": best, "bytes_per_launch": k0_bytes,
            "achieved_GBs": k0_bytes / (best * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
            "frac": k0_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
