@@ -352,7 +352,7 @@ def random_scenes(count=None, seed=None):
     sigma = np.sqrt((375.0 / 2500.0) / 2.0)
     t23 = ["PJ4/K1ABC 37", "K1ABC/7 33", "<PJ4/K1ABC> FK52UD 37"]
     Is, Qs = [], []
-    for scene in range(int(os.environ.get("WSPR_SCENES", "600")) if count is None else count):      # (a longer soak: WSPR_SCENES=1200)
+    for scene in range(int(os.environ.get("WSPR_SCENES", "420")) if count is None else count):      # (a longer soak: WSPR_SCENES=1200)
         I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
         nsig = 0 if scene == 0 else int(rng.integers(1, 7))
         base = rng.uniform(-125, 125, nsig)
