@@ -401,22 +401,21 @@ def shard_block(args, full_host):
     on one GPU is its per-rank shard -- 8 192 single-signal segments -- through the code an 8-rank run takes:
       full_host      the shard with the whole host's CPUs (measured in this process by the caller),
       share_of_8     the same in a child pinned to usable_cpus // 8 CPUs: the host-CPU limit of a rank,
-      rccl_world_1   the same as ONE RANK under torch.distributed.run with the RCCL process group: options broadcast,
-                     per-step SpotGatherer (staging copy, H2D, gather, D2H on rank 0): gather_ms_per_step.
+      rccl_world_1_share_of_8   the same as ONE RANK under torch.distributed.run with the RCCL process group: options
+                     broadcast, per-step SpotGatherer (staging copy, H2D, gather, D2H on rank 0): gather_ms_per_step
+                     (bench.py --config 4 --spawn without the pinning gives the full-host figure: 349-358 k in round 5).
     8 x min(...) is what the sharded run can reach on this host if nothing else limits."""
     share = max(1, usable_cpus() // 8)
     blk = {"workload": full_host["workload"], "full_host": full_host,
            "share_of_8": slim(child_bench(args, 4, 20, 4, cpu_share=share)),
-           "rccl_world_1": slim(child_bench(args, 4, 20, 4, spawn=True)),
            "rccl_world_1_share_of_8": slim(child_bench(args, 4, 20, 4, cpu_share=share, spawn=True))}
-    vals = [v["value"] for v in (blk["full_host"], blk["share_of_8"], blk["rccl_world_1"], blk["rccl_world_1_share_of_8"]) if "value" in v]
-    if len(vals) == 4:
+    vals = [v["value"] for v in (blk["full_host"], blk["share_of_8"], blk["rccl_world_1_share_of_8"]) if "value" in v]
+    if len(vals) == 3:
         blk["share_of_8_over_full_host"] = blk["share_of_8"]["value"] / blk["full_host"]["value"]
         # what the fan-in costs: in the rank's throughput (with it / without it), in CPU time of the driving thread per
         # step, and -- not a cost but a latency: the thread sleeps while its copies and the collective wait their turn
         # in the GPU's queues -- in that thread's wall time
-        blk["with_gather_over_without"] = {"full_host": blk["rccl_world_1"]["value"] / blk["full_host"]["value"],
-                                           "share_of_8": blk["rccl_world_1_share_of_8"]["value"] / blk["share_of_8"]["value"]}
+        blk["with_gather_over_without"] = blk["rccl_world_1_share_of_8"]["value"] / blk["share_of_8"]["value"]
         g = blk["rccl_world_1_share_of_8"]
         if g.get("gather_cpu_ms_per_step") is not None:
             blk["gather_cpu_fraction_of_a_step"] = g["gather_cpu_ms_per_step"] / g["ms_per_step"]
@@ -451,7 +450,7 @@ def host_entry_block(dev, lanes, resident):
     inflight = len(lanes)
     for ex in lanes:
         ex.submit(L.wspr_set_thread_slots, 1).result()
-    for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 8192, 10, 12, 32)):
+    for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 8192, 10, 10, 32)):
         if nsig == 1:
             I, Q, _ = synth_batch_gpu(nseg, 1234, dev, 1, -20.0, -20.0, 1.0)
         else:
@@ -569,12 +568,11 @@ def hashtable_block(dev, lanes):
             for f in pend:
                 f.result()
         flight(0, 2 * nfl)                                      # the lanes' contexts and buffers exist, clocks settled
-        rates = {0: [], 1: []}
-        for use in (0, 1, 0, 1):                                # alternating, so that neither kind has the warmer machine
+        rates = {}
+        for use in (1, 0):
             t0 = time.perf_counter()
-            flight(use, 2 * nfl)
-            rates[use].append(nseg * 2 * nfl / (time.perf_counter() - t0))
-        rates = {k: sum(v) / len(v) for k, v in rates.items()}
+            flight(use, nfl + nfl // 2)
+            rates[use] = nseg * (nfl + nfl // 2) / (time.perf_counter() - t0)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
@@ -1027,7 +1025,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             cnt = min(nseg, 512)
             Ih, Qh = I[:cnt].cpu().numpy(), Q[:cnt].cpu().numpy()
-            cpu, cpu_msgs = cpu_baseline(Ih, Qh, m["expected"][:cnt], 25.0 if args.config == 2 else 20.0)
+            cpu, cpu_msgs = cpu_baseline(Ih, Qh, m["expected"][:cnt], 25.0 if args.config == 2 else 14.0)
             same = sum(1 for i in range(len(cpu_msgs)) if cpu_msgs[i] == m["got"][i])
             cpu["gpu_equals_cpu_spots"] = "%d/%d segments" % (same, len(cpu_msgs))
         secondary = None
