@@ -450,7 +450,9 @@ def host_entry_block(dev, lanes, resident):
     inflight = len(lanes)
     for ex in lanes:
         ex.submit(L.wspr_set_thread_slots, 1).result()
-    for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 8192, 10, 10, 32)):
+    # (configs[2] with HALF its segments per call: the ratio to the resident call is what the block is for, and 2 x 1.5 GB of
+    # host rows per variant keep the default command short)
+    for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 4096, 10, 12, 32)):
         if nsig == 1:
             I, Q, _ = synth_batch_gpu(nseg, 1234, dev, 1, -20.0, -20.0, 1.0)
         else:
@@ -519,7 +521,7 @@ def hashtable_block(dev, lanes):
     import shutil
     import tempfile
     L = w.lib()
-    nseg, K = 8192, 32
+    nseg, K = 2048, 32                       # a quarter of configs[2]'s batch: same traffic, a short block
     I, Q, _ = synth_batch_gpu(nseg, 2468, dev, 10, -10.0, -28.0, 0.3, frac23=0.05)
     torch.cuda.synchronize()
     out = (w.decoder_results * (nseg * K))()
@@ -571,8 +573,8 @@ def hashtable_block(dev, lanes):
         rates = {}
         for use in (1, 0):
             t0 = time.perf_counter()
-            flight(use, nfl + nfl // 2)
-            rates[use] = nseg * (nfl + nfl // 2) / (time.perf_counter() - t0)
+            flight(use, 4 * nfl)
+            rates[use] = nseg * 4 * nfl / (time.perf_counter() - t0)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
@@ -894,7 +896,17 @@ def main():
                 "gather_cpu_ms_per_step": (1e3 * gather_s[2] / gather_s[1]) if gather_s[1] else None}
 
     nseg = args.segments or {2: 1024, 3: 8192, 4: 8192, 5: 1024}[args.config]
+    t_prog = time.perf_counter()
+    walls = {}
+
+    def lap(name):
+        """wall seconds since the previous lap, by block: where the default command's minutes go"""
+        nonlocal t_prog
+        now = time.perf_counter()
+        walls[name] = round(now - t_prog, 1)
+        t_prog = now
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
+    lap("headline (synthesis, untimed and timed steps)")
 
     fanout = None
     if use_dist and args.config != 5:
@@ -1018,6 +1030,7 @@ def main():
                 LL.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
                 roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
                 del src, dst
+        lap("kernel-level roofline, PMC passes, ceilings")
         cpu = None
         if args.config == 5 and roof is not None:
             roof["front_end_K0"] = k0_report(w.lab(), m, world == 1 and not args.no_cpu_baseline)
@@ -1028,6 +1041,7 @@ def main():
             cpu, cpu_msgs = cpu_baseline(Ih, Qh, m["expected"][:cnt], 25.0 if args.config == 2 else 14.0)
             same = sum(1 for i in range(len(cpu_msgs)) if cpu_msgs[i] == m["got"][i])
             cpu["gpu_equals_cpu_spots"] = "%d/%d segments" % (same, len(cpu_msgs))
+        lap("cpu_baseline")
         secondary = None
         if world == 1 and args.config == 3 and not args.no_secondary and not use_dist:
             del I, Q
@@ -1039,6 +1053,7 @@ def main():
                          "ms_per_step": m2["ms_per_step"], "batches_in_flight": m2["inflight"], "slots_per_batch": m2["slots"],
                          "seconds_timed": m2["elapsed"], "decoded_ok": m2["decoded_ok"],
                          "false_decodes": m2["false_decodes"], "stage_ms_last_step": m2["timings"]}
+        lap("secondary")
         tertiary = None
         if world == 1 and args.config == 3 and not args.no_tertiary and not use_dist:
             # configs[4] (raw 2.4 Msps input through the on-GPU decimator) rides along in the default line: its
@@ -1054,6 +1069,7 @@ def main():
                         "front_end_K0": k0_report(w.lab(), m3, not args.no_cpu_baseline)}
             del m3
             torch.cuda.empty_cache()
+        lap("tertiary")
         shard = None
         if world == 1 and args.config == 3 and not args.no_shard_block and not use_dist:
             # configs[3]'s per-rank shard (8 192 single-signal segments): in this process with the whole host, then in
@@ -1070,6 +1086,7 @@ def main():
             torch.cuda.empty_cache()
             L.wspr_release_buffers()
             shard = shard_block(args, full)
+        lap("configs3_shard")
         host_entry = None
         if world == 1 and args.config == 3 and not args.no_host_entry and not use_dist:
             I = Q = None
@@ -1077,10 +1094,12 @@ def main():
             torch.cuda.empty_cache()
             L.wspr_release_buffers()
             host_entry = host_entry_block(dev, lanes[:12], m["value"])
+        lap("host_entry")
         hashtable = None
         if world == 1 and args.config == 3 and not args.no_hashtable_block and not use_dist:
             torch.cuda.empty_cache()
             hashtable = hashtable_block(dev, lanes)
+        lap("usehashtable_batch")
         out = {
             "metric": "2-minute WSPR segments decoded per second", "value": m["value"],
             "unit": "segments/s", "n_gpus": world, "distinct_devices": distinct_devices,
@@ -1114,6 +1133,8 @@ def main():
                 torch.cuda.empty_cache()
                 L.wspr_release_buffers()
                 out["per_rank_share_of_8"] = share_of_8_block(args, inflight)
+        lap("reference case, per_rank_share_of_8")
+        out["wall_seconds_by_block"] = walls
     line = json.dumps(out) if rank == 0 else None
     if use_dist:
         dist.barrier()
