@@ -278,10 +278,10 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
     // One load at a time per device (the turnstile): the lane whose turn it is has the link to itself and its batch in
     // HBM after 1/n of the time n concurrent loads would take -- and starts computing under the next lane's transfer.
     std::unique_lock<std::mutex> turn(host_load_turn(c.device), std::defer_lock);
-    auto finish_turn = [&] {                                     // the turn ends when the LINK is free again, not when
-        HIP_OK(hipEventRecord(c.ev_copy, ld));                   // the copies have merely been queued
-        host_wait(c.ev_copy);
-    };
+    // The turn ends when the link is ABOUT to be free, not when the copies have merely been queued: the event handed to
+    // finish_turn() completes while the call's last piece (half a dense chunk, or one pageable chunk: 0.4-0.8 ms of
+    // DMA) is still on the link, so the next lane's wake-up and queueing (a sleeping wait: up to 250 us) hide under it.
+    auto finish_turn = [&](hipEvent_t nearly_done) { host_wait(nearly_done); };
     if (host_is_pinned(I) && host_is_pinned(Q)) {
         turn.lock();
         // Pinned rows: LINEAR copies (the DMA engines at the link's rate, no CU involved) of up to kDense rows at a time
@@ -294,24 +294,44 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
             !(reinterpret_cast<uintptr_t>(I) & 15) && !(reinterpret_cast<uintptr_t>(Q) & 15)) {
             constexpr int kDense = 256;
             const int per = std::min(nseg, kDense);
-            // two dense buffers in turn: the row kernel of chunk k runs under the DMA of chunk k + 1
-            float* dn0 = static_cast<float*>(c.densein.need((size_t)4 * per * stride * 4));
-            for (int c0 = 0, k = 0; c0 < nseg; c0 += per, ++k) {
-                const int n = std::min(per, nseg - c0);
-                float* dn = dn0 + (size_t)(k & 1) * 2 * per * stride;
-                const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
-                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
-                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
-                if (!launch_load_rows(dn, dn + (size_t)per * stride, stride, samples, n, wi + (size_t)c0 * kIqStride,
-                                      wq + (size_t)c0 * kIqStride, ld))
-                    throw std::runtime_error("load_rows refused an aligned dense chunk");
+            // Two dense buffers in turn, the row kernels on a stream of their own (same priority): the kernel of chunk k
+            // runs under the DMA of chunk k + 1 -- on the copy stream itself it would stand between two copies, and
+            // beside a busy GPU that is 0.1-0.2 ms of idle link per chunk.
+            if (!c.row_stream) {
+                int least = 0, greatest = 0;
+                HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_OK(hipStreamCreateWithPriority(&c.row_stream, hipStreamNonBlocking, greatest));
+                for (int b = 0; b < 2; ++b) {
+                    HIP_OK(hipEventCreateWithFlags(&c.ev_dense[b], hipEventDisableTiming));
+                    HIP_OK(hipEventCreateWithFlags(&c.ev_rows[b], hipEventDisableTiming));
+                }
             }
+            float* dn0 = static_cast<float*>(c.densein.need((size_t)4 * per * stride * 4));
+            const int nchunks = (nseg + per - 1) / per;
+            for (int c0 = 0, k = 0; c0 < nseg; c0 += per, ++k) {
+                const int n = std::min(per, nseg - c0), b = k & 1;
+                float* dn = dn0 + (size_t)b * 2 * per * stride;
+                const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
+                if (k >= 2) HIP_OK(hipStreamWaitEvent(ld, c.ev_rows[b], 0));    // the kernel that read this buffer last
+                HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
+                if (k == nchunks - 1) HIP_OK(hipEventRecord(c.ev_stage[0], ld));
+                HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
+                HIP_OK(hipEventRecord(c.ev_dense[b], ld));
+                HIP_OK(hipStreamWaitEvent(c.row_stream, c.ev_dense[b], 0));
+                if (!launch_load_rows(dn, dn + (size_t)per * stride, stride, samples, n, wi + (size_t)c0 * kIqStride,
+                                      wq + (size_t)c0 * kIqStride, c.row_stream))
+                    throw std::runtime_error("load_rows refused an aligned dense chunk");
+                HIP_OK(hipEventRecord(c.ev_rows[b], c.row_stream));
+            }
+            for (int b = 0; b < std::min(2, nchunks); ++b) HIP_OK(hipStreamWaitEvent(ld, c.ev_rows[b], 0));   // the load ends with its last row kernel
+            if (nseg >= 16) finish_turn(c.ev_stage[0]);
         } else {
             zero_tail(wi, wq, nseg, samples, ld);
             HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
+            HIP_OK(hipEventRecord(c.ev_stage[0], ld));
             HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
+            if (nseg >= 16) finish_turn(c.ev_stage[0]);
         }
-        if (nseg >= 16) finish_turn();
         return;
     }
     if (nseg < 16) {                                             // a single call's record or a handful: the runtime's own path
@@ -367,7 +387,8 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
     send(0);
     if (nchunks > 1) send(1);
     for (int k = 2; k < nchunks; ++k) { gather(k); send(k); }
-    finish_turn();
+    if (nchunks >= 2) finish_turn(c.ev_stage[(nchunks - 2) & 1]);
+    else finish_turn(c.ev_stage[0]);
     // the caller's rows were consumed by the gathers and may change from here on
 }
 void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {

@@ -206,6 +206,8 @@ struct Context::Impl {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr; // host-buffer loads, at the highest stream priority (see load_host)
     hipEvent_t ev_copy = nullptr;
+    hipStream_t row_stream = nullptr;  // pinned host rows: the kernel that spreads a dense chunk, beside the next chunk's DMA
+    hipEvent_t ev_dense[2] = {nullptr, nullptr}, ev_rows[2] = {nullptr, nullptr};
     hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
     int fe_cus = 0;                    // CUs the mask of fe_stream admits (0: fe_stream not in use)
     int device = 0;
