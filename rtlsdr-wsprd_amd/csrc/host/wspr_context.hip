@@ -63,6 +63,7 @@ Context::Context(int nslots) : d(new Impl) {
         HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_OK(hipStreamCreateWithPriority(&d->copy_stream, hipStreamNonBlocking, greatest));
         HIP_OK(hipEventCreateWithFlags(&d->ev_copy, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&d->ev_final, (wait_mode() == 1 ? hipEventBlockingSync : hipEventDefault) | hipEventDisableTiming));
     }
 
     // constant tables, computed with the host libm exactly as the reference does
@@ -224,7 +225,11 @@ static bool host_is_pinned(const void* p) {
 
 // One turnstile per device for the host-buffer loads: calls in flight on several lanes (and the slots of one call) take
 // the PCIe link one after the other instead of sharing it, so the first of them has its data -- and starts computing
-// under the others' transfers -- after 1/n of the time.
+// under the others' transfers -- after 1/n of the time.  A turn ends when the holder's last copy has COMPLETED (a host
+// wait).  Two ways of closing the gap that leaves between two lanes' transfers were measured and dropped
+// (profiles/r05_host_entry_probe_history.txt): ending the turn one chunk early (two lanes then share the link for a
+// moment: +3 % in a process of its own, -20 % inside bench.py's), and handing over on the device (the next lane queues
+// behind the holder's last copy with a stream wait: -3 %, and the same -20 % for pageable rows).
 static std::mutex& host_load_turn(int device) {
     static std::mutex m[Context::kMaxDevices];
     return m[std::max(0, std::min(device, Context::kMaxDevices - 1))];
@@ -275,15 +280,17 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
             (void)hipStreamWaitEvent(c.stream, c.ev_copy, 0);
         }
     } join{c};
-    // One load at a time per device (the turnstile): the lane whose turn it is has the link to itself and its batch in
-    // HBM after 1/n of the time n concurrent loads would take -- and starts computing under the next lane's transfer.
+    // One load at a time per device (host_load_turn()).  A call of a few segments does not queue up (a receiver's
+    // single record must not wait for a batch's 370 MB).
     std::unique_lock<std::mutex> turn(host_load_turn(c.device), std::defer_lock);
-    // The turn ends when the link is ABOUT to be free, not when the copies have merely been queued: the event handed to
-    // finish_turn() completes while the call's last piece (half a dense chunk, or one pageable chunk: 0.4-0.8 ms of
-    // DMA) is still on the link, so the next lane's wake-up and queueing (a sleeping wait: up to 250 us) hide under it.
-    auto finish_turn = [&](hipEvent_t nearly_done) { host_wait(nearly_done); };
+    auto take_turn = [&] { turn.lock(); };
+    auto pass_turn = [&] {                                       // the turn ends when the LINK is free again, not when
+        HIP_OK(hipEventRecord(c.ev_final, ld));                  // the copies have merely been queued
+        host_wait(c.ev_final, 30000L);                           // short naps: the link idles for as long as this thread oversleeps
+    };
+    const bool queues_up = nseg >= 16;
     if (host_is_pinned(I) && host_is_pinned(Q)) {
-        turn.lock();
+        if (queues_up) take_turn();
         // Pinned rows: LINEAR copies (the DMA engines at the link's rate, no CU involved) of up to kDense rows at a time
         // into a dense device buffer, and the row kernel that also serves resident input spreads them into the working
         // layout (device to device, microseconds).  A strided host-to-device copy straight into the working rows measured
@@ -314,7 +321,6 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
                 const size_t fl = (size_t)(n - 1) * stride + samples;           // the last row may end at `samples`
                 if (k >= 2) HIP_OK(hipStreamWaitEvent(ld, c.ev_rows[b], 0));    // the kernel that read this buffer last
                 HIP_OK(hipMemcpyAsync(dn, I + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
-                if (k == nchunks - 1) HIP_OK(hipEventRecord(c.ev_stage[0], ld));
                 HIP_OK(hipMemcpyAsync(dn + (size_t)per * stride, Q + (size_t)c0 * stride, fl * 4, hipMemcpyHostToDevice, ld));
                 HIP_OK(hipEventRecord(c.ev_dense[b], ld));
                 HIP_OK(hipStreamWaitEvent(c.row_stream, c.ev_dense[b], 0));
@@ -323,14 +329,13 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
                     throw std::runtime_error("load_rows refused an aligned dense chunk");
                 HIP_OK(hipEventRecord(c.ev_rows[b], c.row_stream));
             }
+            if (queues_up) pass_turn();
             for (int b = 0; b < std::min(2, nchunks); ++b) HIP_OK(hipStreamWaitEvent(ld, c.ev_rows[b], 0));   // the load ends with its last row kernel
-            if (nseg >= 16) finish_turn(c.ev_stage[0]);
         } else {
             zero_tail(wi, wq, nseg, samples, ld);
             HIP_OK(hipMemcpy2DAsync(wi, (size_t)kIqStride * 4, I, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-            HIP_OK(hipEventRecord(c.ev_stage[0], ld));
             HIP_OK(hipMemcpy2DAsync(wq, (size_t)kIqStride * 4, Q, stride * 4, (size_t)samples * 4, nseg, hipMemcpyHostToDevice, ld));
-            if (nseg >= 16) finish_turn(c.ev_stage[0]);
+            if (queues_up) pass_turn();
         }
         return;
     }
@@ -383,12 +388,11 @@ void Context::load_host(const float* I, const float* Q, int nseg, int samples, s
     const int nchunks = (nseg + chunk - 1) / chunk;
     gather(0);
     if (nchunks > 1) gather(1);
-    turn.lock();
+    take_turn();
     send(0);
     if (nchunks > 1) send(1);
     for (int k = 2; k < nchunks; ++k) { gather(k); send(k); }
-    if (nchunks >= 2) finish_turn(c.ev_stage[(nchunks - 2) & 1]);
-    else finish_turn(c.ev_stage[0]);
+    pass_turn();
     // the caller's rows were consumed by the gathers and may change from here on
 }
 void Context::load_device(const void* dI, const void* dQ, int nseg, int samples, size_t stride) {

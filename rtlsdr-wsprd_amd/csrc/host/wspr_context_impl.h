@@ -48,14 +48,13 @@ inline int wait_mode() {
 // microseconds and its latency is what its caller sees (one wspr_decode() per two minutes), a large batch's take
 // milliseconds and its lanes' CPUs are what the other lanes and ranks need
 inline thread_local int t_spin_us = 40;
-inline void host_wait(hipEvent_t ev) {
+inline void host_wait(hipEvent_t ev, long nap_cap_ns = 250000L) {  // 60 / 120 / 250 / 500 / 1000 us measured alike (profiles/r05_sleep_cap_ab.txt)
     if (wait_mode() != 2) {
         const hipError_t e = hipEventSynchronize(ev);
         if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventSynchronize");
         return;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    constexpr long nap_cap_ns = 250000L;        // 60 / 120 / 250 / 500 / 1000 us measured alike (profiles/r05_sleep_cap_ab.txt)
     long nap_ns = 20000;
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
@@ -206,6 +205,7 @@ struct Context::Impl {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr; // host-buffer loads, at the highest stream priority (see load_host)
     hipEvent_t ev_copy = nullptr;
+    hipEvent_t ev_final = nullptr;     // this context's last host-to-device copy of a load: the turn at the link ends with it
     hipStream_t row_stream = nullptr;  // pinned host rows: the kernel that spreads a dense chunk, beside the next chunk's DMA
     hipEvent_t ev_dense[2] = {nullptr, nullptr}, ev_rows[2] = {nullptr, nullptr};
     hipStream_t fe_stream = nullptr;   // front end (K0) on a CU-masked stream, see front_end_cus()
