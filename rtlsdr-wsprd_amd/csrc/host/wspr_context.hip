@@ -236,10 +236,11 @@ static std::mutex& host_load_turn(int device) {
 }
 
 // The gathers of pageable rows are memcpy-bound (about 9 GB/s per thread here): one pool per process for them, half
-// the CPUs of the rank's share but at most eight threads, used by one gather at a time.
+// the CPUs of the rank's share but at most sixteen threads (4 / 8 / 12 / 16: 0.80 / 0.86-0.87 / 0.89-0.91 / 0.91 of the link on
+// configs[1], profiles/r05_host_entry_probe_history.txt), used by one gather at a time.
 static Pool& gather_pool(std::unique_lock<std::mutex>& hold) {
     static std::mutex m;
-    static Pool pool(std::max(1, std::min(8, rank_cpus() / 2)) - 1);
+    static Pool pool(std::max(1, std::min(16, rank_cpus() / 2)) - 1);
     hold = std::unique_lock<std::mutex>(m);
     return pool;
 }
