@@ -38,7 +38,7 @@ compile_variant() {
       pids+=($!)
     fi
   done
-  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+  for p in "${pids[@]:-}"; do if [ -n "$p" ]; then wait "$p"; fi; done   # (nothing out of date: no pids, and no failure)
 }
 
 # $1 = map file, $2... = headers: exported symbols = exactly the functions and data those headers declare

@@ -37,11 +37,11 @@ int fail(const char* where, const std::exception& e) {
     fprintf(stderr, "libwspr_mi355x: %s failed: %s\n", where, e.what());
     return -1;
 }
-// The callsign hash memory makes a segment's result depend on what was decoded before it
-// (wsprd.c:481-494, 842-852: hashtable.txt read before, written after every decode).  Segments of a batch are
-// normally decoded concurrently; with usehashtable = 1 they are therefore decoded ONE BY ONE IN ORDER, each
-// as the reference's own call would be (load the file, decode, save the file) -- the option is honoured, not
-// dropped, at the price of the batch parallelism.
+#ifdef WSPR_LAB
+// The callsign hash memory makes a segment's result depend on what was decoded before it (wsprd.c:481-494, 842-852:
+// hashtable.txt read before, written after every decode).  The product decodes a usehashtable batch in parallel all the
+// same (decode_hashed() below); the per-candidate TRACE of the lab library keeps the plain form of rounds 2-4: one
+// segment after the other, each as the reference's own call would be (load the file, decode, save the file).
 template <class One>
 int decode_in_order(int nseg, int* n_results, One one) {
     int rc = 0;
@@ -51,6 +51,7 @@ int decode_in_order(int nseg, int* n_results, One one) {
     }
     return rc;
 }
+#endif
 // device scratch of one call, released on every exit path
 struct TempDev {
     void* p = nullptr;
