@@ -15,7 +15,9 @@
  *                        through the receiver session: 65 536-byte callbacks (rtlsdr_wsprd.c:126), a roll-over every
  *                        576 000 000 bytes (the two minutes the main loop counts off the wall clock, :1170-1185), the
  *                        decoder thread's body on the completed buffer (:263-328), printSpots()' lines (:447-474) with
- *                        frame times counted from -T (UTC seconds of the first sample's slot; default 0).
+ *                        frame times counted from -T (UTC seconds of the first sample's slot; default 0).  Repeated,
+ *                        every -i is one more RECEIVER: callbacks in turn, and at the even minute all completed buffers
+ *                        are decoded together (wspr_session_decode_many()); lines carry "[k] " in front.
  *   decoder options      -f dial Hz, -c call, -l locator, -H, -Q, -S as rtlsdr_wsprd.c:862-970.
  *
  * Build: make -C examples      (gcc, links ../rtlsdr-wsprd_amd/libwspr_mi355x.so with an rpath)
@@ -38,7 +40,7 @@ static const char kHeader[] = "        SNR      DT        Freq Dr    Call    Loc
 
 static void usage(const char *argv0) {
     fprintf(stderr,
-            "use: %s [-f dial_hz] [-c call] [-l locator] [-H] [-Q] [-S] (-r FILE [FILE ...] | -t | -i RAWFILE|- [-T utc_seconds])\n",
+            "use: %s [-f dial_hz] [-c call] [-l locator] [-H] [-Q] [-S] (-r FILE [FILE ...] | -t | -i RAWFILE|- [-i RAWFILE ...] [-T utc_seconds])\n",
             argv0);
 }
 
@@ -136,57 +138,77 @@ static int self_test(struct decoder_options opt) {
     return ok ? 0 : 1;
 }
 
-/* ---- -i: a raw receiver stream through the session ---------------------------------------------------------------- */
-static int decode_slot(wspr_session *rx, int buffer, long slot_end_utc, int *total) {
-    struct decoder_results spots[MAX_SPOTS];
-    int n = 0;
-    memset(spots, 0, sizeof spots);
-    const int r = wspr_session_decode(rx, buffer, spots, &n);
-    if (r < 0) { fprintf(stderr, "decode failed (%d): no usable MI355X\n", r); return 3; }
+/* ---- -i: raw receiver streams through sessions -------------------------------------------------------------------- */
+#define MAX_RECEIVERS 64
+
+static int decode_slot(wspr_session **rx, int nrx, const int *buffers, long slot_end_utc, int *total) {
+    struct decoder_results *spots = calloc((size_t)nrx * MAX_SPOTS, sizeof *spots);
+    int nspots[MAX_RECEIVERS], decoded[MAX_RECEIVERS];
+    if (!spots) { fprintf(stderr, "out of memory\n"); return 2; }
+    /* every receiver's completed buffer in one call: the decoder thread's body (rtlsdr_wsprd.c:263-328) for all of them */
+    const int r = wspr_session_decode_many(rx, buffers, nrx, spots, MAX_SPOTS, nspots, decoded);
+    if (r < 0) { fprintf(stderr, "decode failed (%d): no usable MI355X\n", r); free(spots); return 3; }
     int y, mo, d, h, mi;
     wspr_frame_time(slot_end_utc, &y, &mo, &d, &h, &mi);
-    if (r == 0) {
-        printf("Signal too short, skipping (%u samples)\n", wspr_session_fill(rx, buffer));
-        return 0;
-    }
-    if (n == 0) printf("No spot %04d-%02d-%02d %02d:%02dz\n", y, mo, d, h, mi);
-    for (int s = 0; s < n; ++s) {
-        char line[160];
-        wspr_format_spot_timestamped(&spots[s], y, mo, d, h, mi, line, sizeof line);
-        printf("%s\n", line);
+    for (int k = 0; k < nrx; ++k) {
+        char who[16] = "";
+        if (nrx > 1) snprintf(who, sizeof who, "[%d] ", k);
+        if (!decoded[k]) {
+            printf("%sSignal too short, skipping (%u samples)\n", who, wspr_session_fill(rx[k], buffers[k]));
+            continue;
+        }
+        if (nspots[k] == 0) printf("%sNo spot %04d-%02d-%02d %02d:%02dz\n", who, y, mo, d, h, mi);
+        for (int s = 0; s < nspots[k]; ++s) {
+            char line[160];
+            wspr_format_spot_timestamped(&spots[(size_t)k * MAX_SPOTS + s], y, mo, d, h, mi, line, sizeof line);
+            printf("%s%s\n", who, line);
+        }
+        *total += nspots[k];
     }
     fflush(stdout);
-    *total += n;
+    free(spots);
     return 0;
 }
 
-static int stream(const char *path, struct decoder_options opt, long t_first_slot) {
-    FILE *in = strcmp(path, "-") == 0 ? stdin : fopen(path, "rb");
-    if (!in) { fprintf(stderr, "%s: %s\n", path, strerror(errno)); return 2; }
-    wspr_session *rx = wspr_session_create(opt);
-    if (!rx) { fprintf(stderr, "no receiver session: no usable MI355X\n"); return 3; }
+static int stream(int nrx, char **paths, struct decoder_options opt, long t_first_slot) {
+    FILE *in[MAX_RECEIVERS];
+    wspr_session *rx[MAX_RECEIVERS];
+    int live[MAX_RECEIVERS];
+    for (int k = 0; k < nrx; ++k) {
+        in[k] = strcmp(paths[k], "-") == 0 ? stdin : fopen(paths[k], "rb");
+        if (!in[k]) { fprintf(stderr, "%s: %s\n", paths[k], strerror(errno)); return 2; }
+        rx[k] = wspr_session_create(opt);
+        if (!rx[k]) { fprintf(stderr, "no receiver session: no usable MI355X\n"); return 3; }
+        live[k] = 1;
+    }
     static uint8_t buf[CALLBACK_BYTES];
-    unsigned long long in_slot = 0;
+    unsigned long long in_slot = 0;                 /* bytes of the current slot every live receiver has delivered */
     long slot_end = t_first_slot + 120;
-    int rc = 0, total = 0;
-    for (;;) {
-        size_t want = CALLBACK_BYTES;
+    int rc = 0, total = 0, nlive = nrx;
+    while (nlive > 0 && rc == 0) {
+        size_t want = CALLBACK_BYTES, fed = 0;
         if (SLOT_BYTES - in_slot < want) want = (size_t)(SLOT_BYTES - in_slot);   /* the slot ends inside this callback */
-        const size_t got = fread(buf, 1, want, in);
-        const size_t whole = got & ~(size_t)15;                                   /* the front end takes multiples of 16 */
-        if (whole && wspr_session_feed(rx, buf, (uint32_t)whole) < 0) { rc = 3; break; }
-        in_slot += whole;
-        const int eof = got < want;
-        if (in_slot == SLOT_BYTES || (eof && in_slot)) {                          /* the even minute, or the stream's end */
-            const int done = wspr_session_rollover(rx);
-            if ((rc = decode_slot(rx, done, slot_end, &total)) != 0) break;
+        for (int k = 0; k < nrx && rc == 0; ++k) {  /* one callback per receiver, in turn (each RX thread's rtlsdr_callback) */
+            if (!live[k]) continue;
+            const size_t got = fread(buf, 1, want, in[k]);
+            const size_t whole = got & ~(size_t)15;                               /* the front end takes multiples of 16 */
+            if (whole && wspr_session_feed(rx[k], buf, (uint32_t)whole) < 0) rc = 3;
+            if (whole > fed) fed = whole;
+            if (got < want) { live[k] = 0; --nlive; }
+        }
+        in_slot += fed;
+        if (rc == 0 && (in_slot == SLOT_BYTES || (nlive == 0 && in_slot))) {      /* the even minute, or the streams' end */
+            int done[MAX_RECEIVERS];
+            for (int k = 0; k < nrx; ++k) done[k] = wspr_session_rollover(rx[k]);
+            rc = decode_slot(rx, nrx, done, slot_end, &total);
             in_slot = 0;
             slot_end += 120;
         }
-        if (eof) break;
     }
-    wspr_session_destroy(rx);
-    if (in != stdin) fclose(in);
+    for (int k = 0; k < nrx; ++k) {
+        wspr_session_destroy(rx[k]);
+        if (in[k] != stdin) fclose(in[k]);
+    }
     fprintf(stderr, "%d spot(s)\n", total);
     return rc;
 }
@@ -198,7 +220,8 @@ int main(int argc, char **argv) {
     opt.npasses = 2;                                        /* the reference's defaults, rtlsdr_wsprd.c:357-362 */
     opt.subtraction = 1;
     enum { NONE, PLAYBACK, SELFTEST, STREAM } mode = NONE;
-    const char *raw = NULL;
+    char *raw[MAX_RECEIVERS];
+    int nraw = 0;
     long t0 = 0;
     int first_file = 0;
     for (int a = 1; a < argc; ++a) {
@@ -215,7 +238,11 @@ int main(int argc, char **argv) {
             case 'S': opt.subtraction = 0; opt.npasses = 1; break;
             case 't': mode = SELFTEST; break;
             case 'T': t0 = strtol(argv[++a], NULL, 10); break;
-            case 'i': mode = STREAM; raw = argv[++a]; break;
+            case 'i':                                                           /* one receiver per -i */
+                mode = STREAM;
+                if (nraw == MAX_RECEIVERS) { fprintf(stderr, "at most %d receivers\n", MAX_RECEIVERS); return 2; }
+                raw[nraw++] = argv[++a];
+                break;
             case 'r': mode = PLAYBACK; first_file = ++a; a = argc; break;      /* everything behind -r is a file */
             default: usage(argv[0]); return 2;
         }
@@ -225,7 +252,7 @@ int main(int argc, char **argv) {
     switch (mode) {
         case PLAYBACK: return playback(argc - first_file, argv + first_file, opt);
         case SELFTEST: return self_test(opt);
-        case STREAM: return stream(raw, opt, t0);
+        case STREAM: return stream(nraw, raw, opt, t0);
         default: usage(argv[0]); return 2;
     }
 }

@@ -236,6 +236,13 @@ int wspr_session_rollover(wspr_session *s);
  * (:277), else zeroes the tail (:284-288), normalises to a peak of 0.5 (:290-305), calls wspr_decode() (:312-317)
  * and returns 1 (negative: no usable device).  The buffer then holds what the reference's saveSample() would see. */
 int wspr_session_decode(wspr_session *s, int buffer, struct decoder_results *decodes, int *n_results);
+/* Many receivers, one slot: the completed buffers (buffers[k] of sessions[k]) of n sessions decoded TOGETHER -- one
+ * batch call per distinct set of decoder options (the receivers of one band share theirs).  decodes: n rows of
+ * max_results spots; n_results[k]; decoded[k] (optional) = 1 / 0 as wspr_session_decode() would have returned.  Spots
+ * and what the buffers hold afterwards are those of wspr_session_decode() on each session in index order (with
+ * usehashtable: the order of the hash memory).  Returns the number of buffers decoded, negative on error. */
+int wspr_session_decode_many(wspr_session *const *sessions, const int *buffers, int n, struct decoder_results *decodes,
+                             int max_results, int *n_results, int *decoded);
 uint32_t wspr_session_fill(const wspr_session *s, int buffer);
 const float *wspr_session_samples(const wspr_session *s, int buffer, int rail /* 0 = I, 1 = Q */);
 /* Microseconds until the next even UTC minute, :1170-1175 (what the main loop sleeps). */

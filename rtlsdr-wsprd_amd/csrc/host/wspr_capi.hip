@@ -945,11 +945,14 @@ const float* wspr_session_samples(const wspr_session* s, int buffer, int rail) {
     return rail ? s->Q[buffer].data() : s->I[buffer].data();
 }
 
-int wspr_session_decode(wspr_session* s, int buffer, struct decoder_results* decodes, int* n_results) {
-    if (!s || (buffer & ~1) != 0 || !n_results) return -1;
-    *n_results = 0;
+}  // extern "C"
+
+namespace {
+// decoder()'s preparation of a completed buffer, rtlsdr_wsprd.c:277-305: false if it is too short to decode, else
+// the tail zeroed and both rails scaled to a peak of 0.5
+bool session_prepare(wspr_session* s, int buffer) {
     const uint32_t n = s->fill[buffer].load();
-    if (n < kSessionMinSamples) return 0;                  // "Signal too short, skipping!" (:277-280)
+    if (n < kSessionMinSamples) return false;              // "Signal too short, skipping!" (:277-280)
     float* I = s->I[buffer].data();
     float* Q = s->Q[buffer].data();
     for (uint32_t i = n; i < kSessionSamples; ++i) { I[i] = 0.0f; Q[i] = 0.0f; }     // :284-288
@@ -961,8 +964,73 @@ int wspr_session_decode(wspr_session* s, int buffer, struct decoder_results* dec
     }
     const float scale = (float)(0.5 / (double)peak);
     for (uint32_t i = 0; i < kSessionSamples; ++i) { I[i] *= scale; Q[i] *= scale; }
-    const int rc = wspr_decode(I, Q, (int)kSessionSamples, s->opt, decodes, n_results);   // :312-317
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int wspr_session_decode(wspr_session* s, int buffer, struct decoder_results* decodes, int* n_results) {
+    if (!s || (buffer & ~1) != 0 || !n_results) return -1;
+    *n_results = 0;
+    if (!session_prepare(s, buffer)) return 0;
+    const int rc = wspr_decode(s->I[buffer].data(), s->Q[buffer].data(), (int)kSessionSamples, s->opt, decodes, n_results);   // :312-317
     return rc < 0 ? rc : 1;
+}
+
+// Many receivers, one slot: the completed buffers of n sessions decoded TOGETHER -- the decoder thread's body
+// (rtlsdr_wsprd.c:263-328) for every receiver of a service in one batch call per distinct set of decoder options
+// (receivers of one band share theirs; `freq` enters the reported frequency in double precision, so receivers with
+// different options are not folded into one call).  Results, and what the buffers hold afterwards, are those of
+// wspr_session_decode() on each session in index order -- with usehashtable that order is the order of the hash memory.
+int wspr_session_decode_many(wspr_session* const* sessions, const int* buffers, int n, struct decoder_results* decodes,
+                             int max_results, int* n_results, int* decoded) {
+    if (!sessions || !buffers || n < 0 || !decodes || max_results < 1 || !n_results) return -1;
+    for (int k = 0; k < n; ++k) {
+        n_results[k] = 0;
+        if (decoded) decoded[k] = 0;
+        if (!sessions[k] || (buffers[k] & ~1) != 0) return -1;
+    }
+    std::vector<int> ready;
+    for (int k = 0; k < n; ++k)
+        if (session_prepare(sessions[k], buffers[k])) { ready.push_back(k); if (decoded) decoded[k] = 1; }
+    std::vector<char> taken(ready.size(), 0);
+    std::vector<float> I, Q;
+    std::vector<decoder_results> out;
+    std::vector<int> nout, group;
+    for (size_t a = 0; a < ready.size(); ++a) {
+        if (taken[a]) continue;
+        const decoder_options& opt = sessions[ready[a]]->opt;
+        group.clear();
+        for (size_t b = a; b < ready.size(); ++b)
+            if (!taken[b] && std::memcmp(&sessions[ready[b]]->opt, &opt, sizeof opt) == 0) { taken[b] = 1; group.push_back(ready[b]); }
+        const int m = (int)group.size();
+        int rc;
+        if (m == 1) {
+            wspr_session* s = sessions[group[0]];
+            const int b = buffers[group[0]];
+            rc = wspr_decode_batch(s->I[b].data(), s->Q[b].data(), 1, (int)kSessionSamples, kSessionSamples, opt,
+                                   decodes + (size_t)group[0] * max_results, max_results, n_results + group[0], 1);
+        } else {
+            I.resize((size_t)m * kSessionSamples); Q.resize((size_t)m * kSessionSamples);
+            out.assign((size_t)m * max_results, decoder_results{});
+            nout.assign((size_t)m, 0);
+            for (int g = 0; g < m; ++g) {
+                std::memcpy(I.data() + (size_t)g * kSessionSamples, sessions[group[g]]->I[buffers[group[g]]].data(), kSessionSamples * sizeof(float));
+                std::memcpy(Q.data() + (size_t)g * kSessionSamples, sessions[group[g]]->Q[buffers[group[g]]].data(), kSessionSamples * sizeof(float));
+            }
+            rc = wspr_decode_batch(I.data(), Q.data(), m, (int)kSessionSamples, kSessionSamples, opt, out.data(), max_results, nout.data(), 1);
+            if (rc >= 0)
+                for (int g = 0; g < m; ++g) {               // spots, and the residual the single call leaves in the buffer
+                    std::memcpy(decodes + (size_t)group[g] * max_results, out.data() + (size_t)g * max_results, (size_t)nout[g] * sizeof(decoder_results));
+                    n_results[group[g]] = nout[g];
+                    std::memcpy(sessions[group[g]]->I[buffers[group[g]]].data(), I.data() + (size_t)g * kSessionSamples, kSessionSamples * sizeof(float));
+                    std::memcpy(sessions[group[g]]->Q[buffers[group[g]]].data(), Q.data() + (size_t)g * kSessionSamples, kSessionSamples * sizeof(float));
+                }
+        }
+        if (rc < 0) { for (int k = 0; k < n; ++k) n_results[k] = 0; return rc; }
+    }
+    return (int)ready.size();
 }
 
 uint32_t wspr_usec_to_next_slot(long tv_sec, long tv_usec) {                              // :1170-1175

@@ -81,9 +81,12 @@ def test_c_host_raw_stream_through_the_session(exe, tmp_path):
     dev = torch.device("cuda", 0)
     raw, expected = bench.synth_raw_gpu(2, 97531, dev, snr_db=-15.0)
     path = tmp_path / "two_slots.u8"
+    other = tmp_path / "one_slot.u8"
     with open(path, "wb") as fh:
         for s in range(2):
             fh.write(raw[s].cpu().numpy().tobytes())
+    with open(other, "wb") as fh:
+        fh.write(raw[1].cpu().numpy().tobytes())
     del raw
     torch.cuda.empty_cache()
     t0 = 1700000040                                              # 2023-11-14 22:14:00 UTC, an even minute
@@ -95,6 +98,14 @@ def test_c_host_raw_stream_through_the_session(exe, tmp_path):
         call, loc, pwr = msg.split()
         assert line.startswith("Spot :  " + stamp), line
         assert line.split()[-3:] == [call, loc, pwr.lstrip("0") or "0"] or line.split()[-3:] == [call, loc, pwr], line
+    # two receivers: callbacks in turn, both completed buffers decoded together at the even minute
+    r3 = run(exe, "-f", "14095600", "-i", str(path), "-i", str(other), "-T", str(t0))
+    assert r3.returncode == 0, r3.stderr
+    l3 = r3.stdout.splitlines()
+    assert len(l3) == 4, r3.stdout
+    assert l3[0] == "[0] " + lines[0] and l3[2] == "[0] " + lines[1]
+    assert l3[1].startswith("[1] Spot :  2023-11-14 22:14z") and l3[1].split()[-3:] == lines[1].split()[-3:]
+    assert l3[3].startswith("[1] Signal too short")
     # the same bytes on stdin
     with open(path, "rb") as fh:
         r2 = run(exe, "-f", "14095600", "-i", "-", "-T", str(t0), stdin=fh)

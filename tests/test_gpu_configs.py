@@ -551,3 +551,69 @@ def test_calibration_hooks_report_plausible_ceilings(env):
     L.wspr_calib_valu.argtypes = [C.c_int, C.c_void_p]
     assert L.wspr_calib_valu(10, C.addressof(tf)) == 0
     assert 30.0 < tf.value <= 78.7, tf.value                  # the no-FMA vector bound is 78.6 TF/s
+
+
+@pytest.mark.gpu
+def test_many_receivers_one_slot_decoded_together(env):
+    """SURVEY 8 f4, "a many-receiver service": the completed buffers of several receiver sessions go through
+    wspr_session_decode_many() -- one batch call per distinct set of decoder options -- and every receiver gets the
+    spots, the return flag and the residual buffer wspr_session_decode() gives it alone (rtlsdr_wsprd.c:263-328 per
+    receiver).  Four receivers: two on one band, one on another, one that has only just started (too short)."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_rollover.argtypes = [C.c_void_p]
+    L.wspr_session_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_decode_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.wspr_session_samples.restype = C.POINTER(C.c_float)
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    raw, exp = bench.synth_raw_gpu(3, 24680, dev, -17.0)
+    streams = [raw[k].cpu().numpy() for k in range(3)] + [raw[0][: 65536 * 64].cpu().numpy()]
+    del raw
+    torch.cuda.empty_cache()
+    dials = [14095600, 14095600, 7038600, 14095600]
+    K = 50
+
+    def receivers():
+        out = []
+        for host, dial in zip(streams, dials):
+            s = L.wspr_session_create(w.default_options(freq=dial))
+            for pos in range(0, host.size, 1 << 26):                    # any chunking gives the same stream (tested elsewhere)
+                chunk = np.ascontiguousarray(host[pos:pos + (1 << 26)])
+                assert L.wspr_session_feed(s, ol.ptr(chunk), chunk.size) >= 0
+            assert L.wspr_session_rollover(s) == 0
+            out.append(s)
+        return out
+
+    def buffer_of(s):
+        return [np.ctypeslib.as_array(L.wspr_session_samples(s, 0, rail), shape=(NS,)).copy() for rail in (0, 1)]
+
+    alone, together = receivers(), receivers()
+    want = []
+    for s in alone:
+        res = (w.decoder_results * K)()
+        n = C.c_int(0)
+        rc = L.wspr_session_decode(s, 0, res, C.byref(n))
+        want.append((rc, [bytes(res[i].message) for i in range(n.value)], [(res[i].freq, res[i].snr, res[i].dt, res[i].cycles) for i in range(n.value)], buffer_of(s)))
+    arr = (C.c_void_p * 4)(*together)
+    bufs = (C.c_int * 4)(0, 0, 0, 0)
+    res = (w.decoder_results * (4 * K))()
+    nres = (C.c_int * 4)()
+    flags = (C.c_int * 4)()
+    assert L.wspr_session_decode_many(arr, bufs, 4, res, K, nres, flags) == 3
+    for k, s in enumerate(together):
+        rc, msgs, nums, buf = want[k]
+        assert flags[k] == rc and nres[k] == len(msgs)
+        assert [bytes(res[k * K + i].message) for i in range(nres[k])] == msgs
+        assert [(res[k * K + i].freq, res[k * K + i].snr, res[k * K + i].dt, res[k * K + i].cycles) for i in range(nres[k])] == nums
+        got = buffer_of(s)
+        assert np.array_equal(got[0], buf[0]) and np.array_equal(got[1], buf[1]), k
+    assert [want[k][0] for k in range(4)] == [1, 1, 1, 0]
+    for k in range(3):
+        assert any(exp[k][0].encode() in m for m in want[k][1]), (k, exp[k], want[k][1])
+    assert abs(want[2][2][0][0] - want[0][2][0][0]) > 5.0               # 40 m against 20 m: the dial enters the reported MHz
+    for s in alone + together:
+        L.wspr_session_destroy(s)
