@@ -913,6 +913,10 @@ int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
     if (!s || !buf || (len & 15u)) return -1;
     const int caller_lane = Context::lane();
     std::lock_guard<std::mutex> hold(s->feed_mu);
+    // every session's front end runs on the ONE lane reserved for it: the RX threads of several receivers take turns
+    // at its context (stream, staging buffers) -- a callback is ~0.1 ms of it against the 13.65 ms it covers
+    static std::mutex front_end_lane;
+    std::lock_guard<std::mutex> lane_turn(front_end_lane);
     try {
         Context::bind_lane(kFrontEndLane);
         const uint32_t idx = s->active.load();

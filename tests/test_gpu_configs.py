@@ -617,3 +617,53 @@ def test_many_receivers_one_slot_decoded_together(env):
     assert abs(want[2][2][0][0] - want[0][2][0][0]) > 5.0               # 40 m against 20 m: the dial enters the reported MHz
     for s in alone + together:
         L.wspr_session_destroy(s)
+
+
+@pytest.mark.gpu
+def test_two_receivers_fed_from_two_threads(env):
+    """A service has one RX thread per receiver (rtlsdr_wsprd.c:1136-1151 per dongle).  Every session's front end runs on
+    the library's one reserved lane, so two threads feeding two sessions at once must take turns at it: each session's
+    buffer must hold exactly the oracle's stream for ITS bytes (round 5: the lane's context was shared unguarded)."""
+    import threading
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_fill.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_session_fill.restype = C.c_uint32
+    L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.wspr_session_samples.restype = C.POINTER(C.c_float)
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    CB, NCB = 65536, 400
+    O = ol.lib()
+    hosts, want = [], []
+    for seed in (7, 8, 9):
+        host = np.random.default_rng(seed).integers(0, 256, CB * NCB, dtype=np.uint8)
+        ost = O.orc_decim_new()
+        oi, oq = np.zeros(NS, np.float32), np.zeros(NS, np.float32)
+        nout = O.orc_decim_feed(C.c_void_p(ost), ol.ptr(host), host.size, ol.ptr(oi), ol.ptr(oq), 0, NS)
+        O.orc_decim_free(C.c_void_p(ost))
+        hosts.append(host)
+        want.append((nout, oi, oq))
+    sessions = [L.wspr_session_create(w.default_options()) for _ in hosts]
+    errs = []
+
+    def rx(k):
+        for c in range(NCB):
+            chunk = np.ascontiguousarray(hosts[k][c * CB:(c + 1) * CB])
+            if L.wspr_session_feed(sessions[k], ol.ptr(chunk), chunk.size) < 0:
+                errs.append((k, c))
+    threads = [threading.Thread(target=rx, args=(k,)) for k in range(len(hosts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    for k, s in enumerate(sessions):
+        nout, oi, oq = want[k]
+        assert L.wspr_session_fill(s, 0) == nout
+        gi = np.ctypeslib.as_array(L.wspr_session_samples(s, 0, 0), shape=(NS,))
+        gq = np.ctypeslib.as_array(L.wspr_session_samples(s, 0, 1), shape=(NS,))
+        assert np.array_equal(gi[:nout], oi[:nout]) and np.array_equal(gq[:nout], oq[:nout]), k
+        L.wspr_session_destroy(s)
