@@ -314,10 +314,11 @@ int wspr_fano_batch_device_wave(const unsigned char *symbols, int n, unsigned ma
  * involved. */
 int wspr_device_count(void);
 int wspr_set_device(int device);
-/* Concurrency.  Like the reference, the library is not re-entrant within one lane; it keeps up to sixteen
- * independent lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls
- * this (returns the lane actually bound, 0..15; one more lane is reserved for receiver sessions); calls made from
- * threads bound to different lanes may overlap, e.g. to start the next batch under the tail of the current one. */
+/* Concurrency.  Like the reference, the library is not re-entrant within one lane -- calls made on the same lane of
+ * the same device from several threads TAKE TURNS (safe, but nothing overlaps); it keeps up to sixteen independent
+ * lanes (streams, buffers, host pools).  A host thread is bound to lane 0 until it calls this (returns the lane
+ * actually bound, 0..15; one more lane is reserved for receiver sessions); calls made from threads bound to different
+ * lanes may overlap, e.g. to start the next batch under the tail of the current one. */
 int wspr_bind_thread_lane(int lane);
 /* A batch of >= 128 segments is split over up to WSPR_SLOTS (default 3) concurrent pipelines ("slots") of the
  * calling thread's lane, so that one call overlaps its own host phases with its own kernels.  A service that

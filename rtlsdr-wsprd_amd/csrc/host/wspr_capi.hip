@@ -52,6 +52,23 @@ int decode_in_order(int nseg, int* n_results, One one) {
     return rc;
 }
 #endif
+// One call at a time per (device, lane).  The library is not re-entrant within a lane (neither is the reference:
+// global FFTW plan, static state and fixed file names, wsprd.c:81, :133); threads that never bound a lane all sit on
+// lane 0, and until round 5 two of them calling at once shared a context -- streams, working buffers, pools -- silently.
+// Now their calls take turns: slow instead of wrong.  Recursive, because entry points call each other on one thread
+// (wspr_decode -> wspr_decode_batch -> wspr_decode_batch_hashed); the node-level calls do NOT take it (their worker
+// threads bind the caller's lane on each device and call the batch entry points).
+struct LaneTurn {
+    std::unique_lock<std::recursive_mutex> hold;
+    LaneTurn() {
+        static std::recursive_mutex turns[Context::kMaxDevices][Context::kMaxLanes];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        dev = std::max(0, std::min(dev, Context::kMaxDevices - 1));
+        const int lane = std::max(0, std::min(Context::lane(), Context::kMaxLanes - 1));
+        hold = std::unique_lock<std::recursive_mutex>(turns[dev][lane]);
+    }
+};
 // device scratch of one call, released on every exit path
 struct TempDev {
     void* p = nullptr;
@@ -242,6 +259,7 @@ size_t wspr_iq_stride(void) { return (size_t)wspr::kIqStride; }
 int wspr_decode_batch(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                       struct decoder_options options, struct decoder_results* decodes, int max_results,
                       int* n_results, int writeback) {
+    LaneTurn lane_turn;
     if (options.usehashtable && nseg > 1)                 // the hash memory orders the segments: parallel all the same
         return wspr_decode_batch_hashed(idat, qdat, nseg, samples, seg_stride, options, decodes, max_results, n_results,
                                         writeback, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr);
@@ -274,6 +292,7 @@ int wspr_decode_batch_hashed(float* idat, float* qdat, int nseg, int samples, si
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results, int writeback, int seg_index0, const wspr_hash_op* prior, int n_prior,
                              int flags, wspr_hash_op* stores_out, int cap, int* n_stores, int* n_redecoded) {
+    LaneTurn lane_turn;
     try {
         if (samples > wspr::kMaxSamples) {
             fprintf(stderr, "libwspr_mi355x: samples = %d exceeds the %d this library decodes\n", samples, wspr::kMaxSamples);
@@ -311,6 +330,7 @@ int wspr_hash_commit(const wspr_hash_op* stores, int n) {
 int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, size_t seg_stride,
                             struct decoder_options options, struct decoder_results* decodes, int max_results,
                             int* n_results, wspr_trace* trace) {
+    LaneTurn lane_turn;
     if (!trace) return -1;
     if (options.usehashtable && nseg > 1)
         return decode_in_order(nseg, n_results, [&](int s) {
@@ -343,6 +363,7 @@ int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, siz
 int wspr_decode_batch_device(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride,
                              struct decoder_options options, struct decoder_results* decodes, int max_results,
                              int* n_results) {
+    LaneTurn lane_turn;
     try {
         if (samples > wspr::kMaxSamples) {
             // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
@@ -576,6 +597,7 @@ int wspr_decode(float* idat, float* qdat, int samples, struct decoder_options op
 void sync_and_demodulate(float* id, float* qd, long np, unsigned char* symbols, float* freq, int ifmin, int ifmax,
                          float fstep, int* shift, int lagmin, int lagmax, int lagstep, float* drift, int symfac,
                          float* sync, int mode) {
+    LaneTurn lane_turn;
     try {            // symfac scales the soft symbols of mode 2 (wsprd.c:250); the decoder itself always passes 50 (:427)
         Context::get().demod_single(id, qd, np, symbols, freq, ifmin, ifmax, fstep, shift, lagmin, lagmax, lagstep,
                                     drift, sync, mode, symfac);
@@ -584,12 +606,14 @@ void sync_and_demodulate(float* id, float* qd, long np, unsigned char* symbols, 
 
 void subtract_signal2(float* id, float* qd, long np, float f0, int shift, float drift,
                       const unsigned char* channel_symbols) {
+    LaneTurn lane_turn;
     try { Context::get().subtract_single(id, qd, np, f0, shift, drift, channel_symbols); }
     catch (const std::exception& e) { fail("subtract_signal2", e); }
 }
 
 void subtract_signal(float* id, float* qd, long np, float f0, int shift, float drift,
                      const unsigned char* channel_symbols) {
+    LaneTurn lane_turn;
     try { Context::get().subtract_symbolwise_single(id, qd, np, f0, shift, drift, channel_symbols); }
     catch (const std::exception& e) { fail("subtract_signal", e); }
 }
@@ -597,6 +621,7 @@ void subtract_signal(float* id, float* qd, long np, float f0, int shift, float d
 #ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
                         float* ps_out) {
+    LaneTurn lane_turn;
     try {
         Context& c = Context::get();
         const int blocks = 4 * (samples / wspr::kFftSize) - 1;
@@ -619,6 +644,7 @@ int wspr_stage_fft_bank(const float* idat, const float* qdat, int nseg, int samp
 int wspr_stage_candidates(const float* idat, const float* qdat, int nseg, int samples, size_t seg_stride,
                           int coarse, int maxdrift, struct cand* cand_out, int* npk_out, float* noise_out,
                           float* smspec_out) {
+    LaneTurn lane_turn;
     try {
         Context& c = Context::get();
         c.load_host(idat, qdat, nseg, samples, seg_stride);
@@ -672,6 +698,7 @@ int wspr_last_timings(double* ms, int capacity) {
 #ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,
                         double* ms) {
+    LaneTurn lane_turn;
     try {
         Context& c = Context::get();
         c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
@@ -681,6 +708,7 @@ int wspr_bench_fft_sync(const void* d_idat, const void* d_qdat, int nseg, int sa
 
 int wspr_bench_valu(const void* d_idat, const void* d_qdat, int nseg, int samples, size_t seg_stride, int iters,
                     double* ms) {
+    LaneTurn lane_turn;
     try {
         Context& c = Context::get();
         c.load_device(d_idat, d_qdat, nseg, samples, seg_stride);
@@ -790,6 +818,7 @@ int wspr_set_fano_device_mode(int mode) {
 
 int wspr_fano_batch_device_wave(const unsigned char* symbols, int n, unsigned maxcycles, int* ret, unsigned* cycles,
                                 unsigned* metric, unsigned* maxnp, unsigned char* data, unsigned* steps) {
+    LaneTurn lane_turn;
     try {
         return Context::get().fano_batch(symbols, n, maxcycles, ret, cycles, metric, maxnp, data, steps);
     } catch (const std::exception& e) { return fail("wspr_fano_batch_device_wave", e); }
@@ -798,6 +827,7 @@ int wspr_fano_batch_device_wave(const unsigned char* symbols, int n, unsigned ma
 #ifdef WSPR_LAB   /* include/wspr_mi355x_bench.h: lab build only */
 int wspr_bench_decimate(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat, int iters,
                         double* ms) {
+    LaneTurn lane_turn;
     try {
         return Context::get().bench_decimate(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, iters, ms);
     } catch (const std::exception& e) { return fail("wspr_bench_decimate", e); }
@@ -812,6 +842,7 @@ int wspr_calib_read(const void* d_raw, size_t bytes_per_seg, int nseg, int iters
 
 int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_idat, void* d_qdat,
                                   int normalise) {
+    LaneTurn lane_turn;
     try {
         // rows are read with aligned 16-byte vector loads (a misaligned row stride would also let the last vector of
         // the last row run past the caller's allocation)
@@ -825,6 +856,7 @@ int wspr_decimate_u8_batch_device(const void* d_raw, size_t bytes_per_seg, int n
 
 int wspr_decimate_u8_batch_device_stateful(const void* d_raw, size_t bytes_per_seg, int nseg, void* d_states,
                                            void* d_idat, void* d_qdat, int* n_out) {
+    LaneTurn lane_turn;
     try {
         if (!d_states || (bytes_per_seg & 15)) return -1;
         return Context::get().decimate_device(d_raw, bytes_per_seg, nseg, (float*)d_idat, (float*)d_qdat, 0, n_out,
@@ -840,6 +872,7 @@ void wspr_decim_stream_reset(wspr_decim_state* st) {
 
 int wspr_decimate_u8_stream(wspr_decim_state* st, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
                             uint32_t capacity, uint32_t* new_fill) {
+    LaneTurn lane_turn;
     static_assert(sizeof(wspr_decim_state) == sizeof(wspr::DecimState), "public and device state layouts differ");
     try {
         if (!st || (nbytes & 15)) return -1;
@@ -849,6 +882,7 @@ int wspr_decimate_u8_stream(wspr_decim_state* st, const uint8_t* iq, size_t nbyt
 }
 
 int wspr_decimate_u8(const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t* n_out, int normalise) {
+    LaneTurn lane_turn;
     try {
         Context& c = Context::get();
         nbytes &= ~(size_t)7;

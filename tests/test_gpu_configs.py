@@ -667,3 +667,43 @@ def test_two_receivers_fed_from_two_threads(env):
         gq = np.ctypeslib.as_array(L.wspr_session_samples(s, 0, 1), shape=(NS,))
         assert np.array_equal(gi[:nout], oi[:nout]) and np.array_equal(gq[:nout], oq[:nout]), k
         L.wspr_session_destroy(s)
+
+
+@pytest.mark.gpu
+def test_threads_that_never_bound_a_lane_take_turns(env):
+    """The library is not re-entrant within a lane (neither is the reference, wsprd.c:81, :133) and every thread sits on
+    lane 0 until it binds another.  Two such threads calling at once used to share lane 0's context silently; since round 5
+    their calls take turns.  Three unbound threads decode three different batches four times each, concurrently: every
+    result equals the same batch decoded alone."""
+    import threading
+    torch, bench, w, dev = env
+    L = w.lib()
+    K, nseg = 16, 96
+    opt = w.default_options()
+    batches = []
+    for seed in (11, 12, 13):
+        I, Q, _ = bench.synth_batch_gpu(nseg, seed, dev, 3, -12.0, -24.0, 0.5)
+        batches.append((I.cpu().numpy()[:, :NS].copy(), Q.cpu().numpy()[:, :NS].copy()))
+    torch.cuda.synchronize()
+
+    def decode(k):
+        I, Q = batches[k]
+        out = (w.decoder_results * (nseg * K))()
+        n = (C.c_int * nseg)()
+        assert L.wspr_decode_batch(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, opt, C.addressof(out), K, C.addressof(n), 0) == 0
+        return [[(bytes(out[s * K + i].message), out[s * K + i].freq, out[s * K + i].snr, out[s * K + i].cycles) for i in range(n[s])]
+                for s in range(nseg)]
+    alone = [decode(k) for k in range(3)]
+    assert sum(len(x) for x in alone[0]) > nseg
+    got = [[] for _ in range(3)]
+
+    def worker(k):                                   # a fresh thread: bound to lane 0 like every other
+        for _ in range(4):
+            got[k].append(decode(k))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(3):
+        assert len(got[k]) == 4 and all(g == alone[k] for g in got[k]), k
