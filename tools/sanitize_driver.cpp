@@ -2,7 +2,8 @@
 // program -- no Python interpreter in the process -- linked against a build of the LAB library whose HOST code is
 // instrumented (tools/sanitize.sh: AddressSanitizer + UndefinedBehaviorSanitizer, or ThreadSanitizer).  It walks the
 // threaded host paths: slots of one call, lanes of several calls, the pinned chunk ring of the host-buffer entry, the
-// batch hash memory's rounds, a receiver session whose feed / roll-over / decode run on three threads, the node-level
+// batch hash memory's rounds, a receiver session whose feed / roll-over / decode run on three threads, three receivers fed by
+// three RX threads and decoded together, three threads sharing lane 0, the node-level
 // call folded onto lanes, buffer release.  "host" = the part that needs no GPU (message layer, file formats, hash file).
 // Every check is a plain comparison; the sanitizers report on their own.
 #include <atomic>
@@ -201,6 +202,44 @@ static void gpu_part(int nseg) {
         stop.store(true);
         rx.join();
         wspr_session_destroy(ss);
+    }
+    // 4b. three receivers, one RX thread each (their front ends share the library's reserved lane: turns), and their
+    //     completed buffers decoded together
+    {
+        wspr_session* rx[3];
+        std::vector<std::thread> th;
+        for (int k = 0; k < 3; ++k) { rx[k] = wspr_session_create(options()); CHECK(rx[k] != nullptr); }
+        for (int k = 0; k < 3; ++k)
+            th.emplace_back([&, k] {
+                std::vector<uint8_t> raw(65536);
+                std::mt19937 rng(50 + k);
+                for (auto& b : raw) b = (uint8_t)(120 + rng() % 16);
+                for (int c = 0; c < 150; ++c) CHECK(wspr_session_feed(rx[k], raw.data(), (uint32_t)raw.size()) >= 0);
+            });
+        for (auto& t : th) t.join();
+        int bufs[3], nres[3], flags[3];
+        for (int k = 0; k < 3; ++k) bufs[k] = wspr_session_rollover(rx[k]);
+        std::vector<decoder_results> d(3 * 8);
+        CHECK(wspr_session_decode_many(rx, bufs, 3, d.data(), 8, nres, flags) == 0);      // 150 callbacks: too short, all three
+        CHECK(wspr_session_fill(rx[0], bufs[0]) == wspr_session_fill(rx[1], bufs[1]) && wspr_session_fill(rx[0], bufs[0]) > 700);
+        for (int k = 0; k < 3; ++k) wspr_session_destroy(rx[k]);
+    }
+    // 4c. threads that never bound a lane: all on lane 0, their calls take turns; results must be the first call's
+    {
+        const int part = std::min(nseg, 64);
+        std::vector<std::vector<int>> n(3, std::vector<int>(part));
+        std::vector<std::vector<decoder_results>> r(3, std::vector<decoder_results>((size_t)part * 8));
+        std::vector<std::thread> th;
+        for (int k = 0; k < 3; ++k)
+            th.emplace_back([&, k] {
+                for (int rep = 0; rep < 2; ++rep)
+                    CHECK(wspr_decode_batch(I.data(), Q.data(), part, NS, NS, options(), r[k].data(), 8, n[k].data(), 0) == 0);
+            });
+        for (auto& t : th) t.join();
+        for (int k = 0; k < 3; ++k) {
+            CHECK(std::equal(n[k].begin(), n[k].end(), n0.begin()));
+            CHECK(memcmp(r[k].data(), r0.data(), (size_t)part * 8 * sizeof(decoder_results)) == 0);
+        }
     }
     // 5. the node-level call folded onto lanes of this one device (lab hook)
     {
