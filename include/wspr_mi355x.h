@@ -328,8 +328,9 @@ int wspr_set_thread_slots(int n);
 /* Memory.  The library keeps the work buffers of every (device, lane, slot) it has used, sized for the largest
  * batch seen there (about 1 MB of HBM per segment).  This returns the work buffers of the CURRENT device -- all
  * lanes, device and pinned host memory -- to the driver and reports the device bytes freed; tables, streams and
- * host pools stay, and the next call allocates what it needs.  No other call of the library may be in flight on
- * that device.  Nothing a caller can observe lives in these buffers between calls. */
+ * host pools stay, and the next call allocates what it needs.  Calls in flight on that device (any lane, any
+ * receiver session's feed) finish first and calls arriving meanwhile wait (since round 5; before, none was allowed
+ * to be in flight).  Nothing a caller can observe lives in these buffers between calls. */
 size_t wspr_release_buffers(void);
 /* Scheduler tuning for crowded bands (batches of >= 256 segments per slot): the host Fano pool gives
  * every attempt `cycles_per_bit` cycles per bit; attempts still running then are finished by K6 with

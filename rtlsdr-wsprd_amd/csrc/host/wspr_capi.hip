@@ -58,15 +58,24 @@ int decode_in_order(int nseg, int* n_results, One one) {
 // Now their calls take turns: slow instead of wrong.  Recursive, because entry points call each other on one thread
 // (wspr_decode -> wspr_decode_batch -> wspr_decode_batch_hashed); the node-level calls do NOT take it (their worker
 // threads bind the caller's lane on each device and call the batch entry points).
-struct LaneTurn {
+std::recursive_mutex& lane_turn_of(int dev, int lane) {
+    static std::recursive_mutex turns[Context::kMaxDevices][Context::kMaxLanes];
+    return turns[std::max(0, std::min(dev, Context::kMaxDevices - 1))][std::max(0, std::min(lane, Context::kMaxLanes - 1))];
+}
+int current_device_or_0() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+struct LaneTurn {                                  // the calling thread's lane of the current device
     std::unique_lock<std::recursive_mutex> hold;
-    LaneTurn() {
-        static std::recursive_mutex turns[Context::kMaxDevices][Context::kMaxLanes];
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-        dev = std::max(0, std::min(dev, Context::kMaxDevices - 1));
-        const int lane = std::max(0, std::min(Context::lane(), Context::kMaxLanes - 1));
-        hold = std::unique_lock<std::recursive_mutex>(turns[dev][lane]);
+    LaneTurn() : hold(lane_turn_of(current_device_or_0(), Context::lane())) {}
+};
+struct AllLanesTurn {                              // every lane of the current device, in index order (wspr_release_buffers)
+    std::vector<std::unique_lock<std::recursive_mutex>> hold;
+    AllLanesTurn() {
+        const int dev = current_device_or_0();
+        for (int lane = 0; lane < Context::kMaxLanes; ++lane) hold.emplace_back(lane_turn_of(dev, lane));
     }
 };
 // device scratch of one call, released on every exit path
@@ -795,6 +804,7 @@ int wspr_set_thread_slots(int n) {
 
 size_t wspr_release_buffers(void) {
     try {
+        AllLanesTurn every_lane;                   // calls in flight on this device finish first; new ones wait
         return Context::release_buffers();
     } catch (const std::exception& e) {
         fprintf(stderr, "libwspr_mi355x: wspr_release_buffers failed: %s\n", e.what());
@@ -947,12 +957,11 @@ int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
     if (!s || !buf || (len & 15u)) return -1;
     const int caller_lane = Context::lane();
     std::lock_guard<std::mutex> hold(s->feed_mu);
-    // every session's front end runs on the ONE lane reserved for it: the RX threads of several receivers take turns
-    // at its context (stream, staging buffers) -- a callback is ~0.1 ms of it against the 13.65 ms it covers
-    static std::mutex front_end_lane;
-    std::lock_guard<std::mutex> lane_turn(front_end_lane);
     try {
         Context::bind_lane(kFrontEndLane);
+        // every session's front end runs on the ONE lane reserved for it: the RX threads of several receivers take
+        // turns at its context (stream, staging buffers) -- a callback is ~0.1 ms of it against the 13.65 ms it covers
+        LaneTurn lane_turn;
         const uint32_t idx = s->active.load();
         uint32_t nf = s->fill[idx].load();
         const int rc = Context::get().decimate_stream(&s->dec, buf, len, s->I[idx].data(), s->Q[idx].data(), nf,

@@ -707,3 +707,46 @@ def test_threads_that_never_bound_a_lane_take_turns(env):
         t.join()
     for k in range(3):
         assert len(got[k]) == 4 and all(g == alone[k] for g in got[k]), k
+
+
+@pytest.mark.gpu
+def test_release_buffers_waits_for_calls_in_flight(env):
+    """wspr_release_buffers() frees the work buffers of every lane of the device.  It used to require that no call be in
+    flight; since round 5 it takes every lane's turn first.  Two lanes decode in a loop while the main thread releases the
+    buffers eight times in between: every decode still returns the spots of the quiet decode."""
+    import threading
+    import time
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_release_buffers.restype = C.c_size_t
+    K, nseg = 16, 160
+    opt = w.default_options()
+    I, Q, _ = bench.synth_batch_gpu(nseg, 21, dev, 2, -14.0, -22.0, 0.5)
+    Ih, Qh = I.cpu().numpy()[:, :NS].copy(), Q.cpu().numpy()[:, :NS].copy()
+    torch.cuda.synchronize()
+
+    def decode():
+        out = (w.decoder_results * (nseg * K))()
+        n = (C.c_int * nseg)()
+        assert L.wspr_decode_batch(ol.ptr(Ih), ol.ptr(Qh), nseg, NS, NS, opt, C.addressof(out), K, C.addressof(n), 0) == 0
+        return [[(bytes(out[s * K + i].message), out[s * K + i].cycles) for i in range(n[s])] for s in range(nseg)]
+    quiet = decode()
+    stop = threading.Event()
+    bad = []
+
+    def worker(lane):
+        assert L.wspr_bind_thread_lane(lane) == lane
+        while not stop.is_set():
+            if decode() != quiet:
+                bad.append(lane)
+    threads = [threading.Thread(target=worker, args=(lane,)) for lane in (1, 2)]
+    for t in threads:
+        t.start()
+    freed = 0
+    for _ in range(8):
+        time.sleep(0.05)
+        freed += L.wspr_release_buffers()
+    stop.set()
+    for t in threads:
+        t.join()
+    assert not bad and freed > 0
