@@ -16,8 +16,9 @@
  *                        576 000 000 bytes (the two minutes the main loop counts off the wall clock, :1170-1185), the
  *                        decoder thread's body on the completed buffer (:263-328), printSpots()' lines (:447-474) with
  *                        frame times counted from -T (UTC seconds of the first sample's slot; default 0).  Repeated,
- *                        every -i is one more RECEIVER: callbacks in turn, and at the even minute all completed buffers
- *                        are decoded together (wspr_session_decode_many()); lines carry "[k] " in front.
+ *                        every -i is one more RECEIVER: one callback of each goes to the GPU together
+ *                        (wspr_session_feed_many()), and at the even minute all completed buffers are decoded together
+ *                        (wspr_session_decode_many()); lines carry "[k] " in front.
  *   decoder options      -f dial Hz, -c call, -l locator, -H, -Q, -S as rtlsdr_wsprd.c:862-970.
  *
  * Build: make -C examples      (gcc, links ../rtlsdr-wsprd_amd/libwspr_mi355x.so with an rpath)
@@ -181,21 +182,33 @@ static int stream(int nrx, char **paths, struct decoder_options opt, long t_firs
         if (!rx[k]) { fprintf(stderr, "no receiver session: no usable MI355X\n"); return 3; }
         live[k] = 1;
     }
-    static uint8_t buf[CALLBACK_BYTES];
+    static uint8_t buf[MAX_RECEIVERS][CALLBACK_BYTES];
     unsigned long long in_slot = 0;                 /* bytes of the current slot every live receiver has delivered */
     long slot_end = t_first_slot + 120;
     int rc = 0, total = 0, nlive = nrx;
     while (nlive > 0 && rc == 0) {
         size_t want = CALLBACK_BYTES, fed = 0;
         if (SLOT_BYTES - in_slot < want) want = (size_t)(SLOT_BYTES - in_slot);   /* the slot ends inside this callback */
-        for (int k = 0; k < nrx && rc == 0; ++k) {  /* one callback per receiver, in turn (each RX thread's rtlsdr_callback) */
+        wspr_session *full[MAX_RECEIVERS];          /* receivers whose callback is complete: fed together */
+        const uint8_t *full_buf[MAX_RECEIVERS];
+        int nfull = 0;
+        for (int k = 0; k < nrx && rc == 0; ++k) {  /* one callback per receiver (each RX thread's rtlsdr_callback) */
             if (!live[k]) continue;
-            const size_t got = fread(buf, 1, want, in[k]);
-            const size_t whole = got & ~(size_t)15;                               /* the front end takes multiples of 16 */
-            if (whole && wspr_session_feed(rx[k], buf, (uint32_t)whole) < 0) rc = 3;
+            const size_t got = fread(buf[k], 1, want, in[k]);
+            if (got == want) {
+                full[nfull] = rx[k];
+                full_buf[nfull++] = buf[k];
+                fed = want;
+                continue;
+            }
+            const size_t whole = got & ~(size_t)15;                               /* a stream's last bytes: multiples of 16 */
+            if (whole && wspr_session_feed(rx[k], buf[k], (uint32_t)whole) < 0) rc = 3;
             if (whole > fed) fed = whole;
-            if (got < want) { live[k] = 0; --nlive; }
+            live[k] = 0;
+            --nlive;
         }
+        if (rc == 0 && nfull == 1 && wspr_session_feed(full[0], full_buf[0], (uint32_t)want) < 0) rc = 3;
+        if (rc == 0 && nfull > 1 && wspr_session_feed_many(full, full_buf, (uint32_t)want, nfull, NULL) < 0) rc = 3;
         in_slot += fed;
         if (rc == 0 && (in_slot == SLOT_BYTES || (nlive == 0 && in_slot))) {      /* the even minute, or the streams' end */
             int done[MAX_RECEIVERS];

@@ -229,6 +229,10 @@ void wspr_session_destroy(wspr_session *s);
 /* rtlsdr_callback(buf, len), :126-244: mixer + CIC + FIR into the active buffer (outputs beyond 45000 are
  * dropped, :236-242).  len a multiple of 16 (librtlsdr delivers 65536).  Returns the buffer's fill, < 0 on error. */
 int wspr_session_feed(wspr_session *s, const uint8_t *buf, uint32_t len);
+/* One callback of EACH of n receivers at once (bufs[k]: len bytes for sessions[k]; the same len, a multiple of 16, for
+ * all; the sessions distinct): what n wspr_session_feed() calls do, as one transfer and one launch set -- a callback's
+ * cost is its round trips, not its arithmetic.  fills[k] (optional): sessions[k]'s fill afterwards.  0, < 0 on error. */
+int wspr_session_feed_many(wspr_session *const *sessions, const uint8_t *const *bufs, uint32_t len, int n, int *fills);
 /* Main loop on the 2-minute boundary, :1179-1182: switches to the other buffer (fill reset to 0) and returns the
  * index of the buffer that just completed. */
 int wspr_session_rollover(wspr_session *s);

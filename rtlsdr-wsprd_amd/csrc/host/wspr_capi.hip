@@ -976,6 +976,45 @@ int wspr_session_feed(wspr_session* s, const uint8_t* buf, uint32_t len) {
     }
 }
 
+int wspr_session_feed_many(wspr_session* const* sessions, const uint8_t* const* bufs, uint32_t len, int n, int* fills) {
+    if (!sessions || !bufs || n < 0 || (len & 15u)) return -1;
+    if (n == 0) return 0;
+    std::vector<wspr_session*> order(sessions, sessions + n);
+    for (int k = 0; k < n; ++k) if (!sessions[k] || !bufs[k]) return -1;
+    std::sort(order.begin(), order.end());                      // one locking order for every caller; duplicates refused
+    if (std::adjacent_find(order.begin(), order.end()) != order.end()) return -1;
+    std::vector<std::unique_lock<std::mutex>> held;
+    for (wspr_session* s : order) held.emplace_back(s->feed_mu);
+    const int caller_lane = Context::lane();
+    try {
+        Context::bind_lane(kFrontEndLane);
+        LaneTurn lane_turn;
+        std::vector<wspr::DecimState*> st(n);
+        std::vector<float*> I(n), Q(n);
+        std::vector<uint32_t> fill(n), nf(n);
+        std::vector<uint32_t> idx(n);
+        for (int k = 0; k < n; ++k) {
+            idx[k] = sessions[k]->active.load();
+            st[k] = &sessions[k]->dec;
+            I[k] = sessions[k]->I[idx[k]].data();
+            Q[k] = sessions[k]->Q[idx[k]].data();
+            fill[k] = sessions[k]->fill[idx[k]].load();
+        }
+        const int rc = Context::get().decimate_stream_many(st.data(), bufs, len, n, I.data(), Q.data(), fill.data(),
+                                                           kSessionSamples, nf.data());
+        Context::bind_lane(caller_lane);
+        if (rc) return rc;
+        for (int k = 0; k < n; ++k) {
+            sessions[k]->fill[idx[k]].store(nf[k]);
+            if (fills) fills[k] = (int)nf[k];
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        Context::bind_lane(caller_lane);
+        return fail("wspr_session_feed_many", e);
+    }
+}
+
 int wspr_session_rollover(wspr_session* s) {
     if (!s) return -1;
     std::lock_guard<std::mutex> hold(s->feed_mu);            // not while a callback's outputs are still on their way

@@ -188,7 +188,7 @@ size_t Context::release_buffers() {
                               &c.fz_dat, &c.fz_steps, &c.fz_pool, &c.streamraw, &c.streamstate})
                 freed += b->release();
             for (PinBuf* b : {&c.h_npk, &c.h_cand, &c.h_items, &c.h_sync, &c.h_sym, &c.h_rms, &c.h_jobs, &c.h_jobs2, &c.h_seglist,
-                              &c.h_misc, &c.h_lists, &c.h_fz, &c.h_stage[0], &c.h_stage[1]})
+                              &c.h_misc, &c.h_lists, &c.h_fz, &c.h_stage[0], &c.h_stage[1], &c.h_streamraw, &c.h_streamstate, &c.h_streamout})
                 b->release();
             c.stage_samples[0] = c.stage_samples[1] = 0;
             free(c.hash_arena);
@@ -579,6 +579,52 @@ int Context::decimate_stream(DecimState* h_state, const uint8_t* iq, size_t nbyt
         HIP_OK(hipMemcpy(Q + fill, wq, (size_t)take * 4, hipMemcpyDeviceToHost));
     }
     if (new_fill) *new_fill = fill + take;
+    return 0;
+}
+
+// One chunk of each of n receivers' streams: what n calls of decimate_stream() do, as ONE host-to-device transfer, one
+// launch set over n rows with n carried states, and three transfers back (states, the rows' first outputs per rail).
+// A callback of 65 536 bytes yields five or six samples: its cost is the round trips, not the arithmetic.
+int Context::decimate_stream_many(DecimState* const* h_states, const uint8_t* const* iq, size_t nbytes, int n, float* const* I,
+                                  float* const* Q, const uint32_t* fill, uint32_t cap, uint32_t* new_fill) {
+    Impl& c = *d;
+    if (n <= 0 || nbytes == 0) { for (int k = 0; k < n; ++k) new_fill[k] = fill[k]; return 0; }
+    const int maxout = (int)(nbytes / 2 / 6401) + 2;                       // outputs a chunk of this size can yield
+    const size_t ocols = (size_t)((maxout + 3) & ~3);
+    uint8_t* h_raw = static_cast<uint8_t*>(c.h_streamraw.need((size_t)n * nbytes));
+    DecimState* h_st = static_cast<DecimState*>(c.h_streamstate.need((size_t)n * sizeof(DecimState) + (size_t)n * 4));
+    int* h_nout = reinterpret_cast<int*>(h_st + n);
+    float* h_out = static_cast<float*>(c.h_streamout.need(2 * (size_t)n * ocols * 4));
+    for (int k = 0; k < n; ++k) {
+        memcpy(h_raw + (size_t)k * nbytes, iq[k], nbytes);
+        h_st[k] = *h_states[k];
+    }
+    uint8_t* d_raw = static_cast<uint8_t*>(c.streamraw.need((size_t)n * nbytes + 16));
+    DecimState* d_st = static_cast<DecimState*>(c.streamstate.need((size_t)n * sizeof(DecimState)));
+    HIP_OK(hipMemcpyAsync(d_raw, h_raw, (size_t)n * nbytes, hipMemcpyHostToDevice, c.stream));
+    HIP_OK(hipMemcpyAsync(d_st, h_st, (size_t)n * sizeof(DecimState), hipMemcpyHostToDevice, c.stream));
+    float* wi = work_i(n);
+    float* wq = work_q(n);
+    const size_t nblocks = (size_t)decimate_blocks(nbytes / 2, true);
+    if (nblocks == 0) return -1;
+    int32_t* scratch = static_cast<int32_t*>(c.decscratch.need((size_t)n * nblocks * 24));
+    int* d_nv = static_cast<int*>(c.nvalid.need((size_t)n * 4));
+    launch_decimate(d_raw, nbytes, n, wi, wq, d_nv, scratch, c.stream, d_st);
+    HIP_OK(hipMemcpyAsync(h_nout, d_nv, (size_t)n * 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(h_st, d_st, (size_t)n * sizeof(DecimState), hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpy2DAsync(h_out, ocols * 4, wi, (size_t)kIqStride * 4, ocols * 4, n, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpy2DAsync(h_out + (size_t)n * ocols, ocols * 4, wq, (size_t)kIqStride * 4, ocols * 4, n, hipMemcpyDeviceToHost, c.stream));
+    sync();
+    for (int k = 0; k < n; ++k) {
+        *h_states[k] = h_st[k];
+        const uint32_t room = fill[k] < cap ? cap - fill[k] : 0u;
+        const uint32_t take = std::min<uint32_t>((uint32_t)std::max(0, std::min(h_nout[k], maxout)), room);   // beyond the capacity: dropped
+        if (take) {                                                                          // (rtlsdr_wsprd.c:236-242)
+            memcpy(I[k] + fill[k], h_out + (size_t)k * ocols, (size_t)take * 4);
+            memcpy(Q[k] + fill[k], h_out + (size_t)n * ocols + (size_t)k * ocols, (size_t)take * 4);
+        }
+        new_fill[k] = fill[k] + take;
+    }
     return 0;
 }
 

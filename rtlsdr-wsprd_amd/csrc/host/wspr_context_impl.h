@@ -222,6 +222,7 @@ struct Context::Impl {
     PinBuf h_fz;                     // K6w's results on their way to the host (a copy into pageable memory would make
                                      // the runtime wait for the search itself, on a CPU)
     PinBuf h_stage[2];
+    PinBuf h_streamraw, h_streamstate, h_streamout;   // many receivers' callbacks at once (decimate_stream_many)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     int stage_samples[2] = {0, 0};   // columns [samples, kIqStride) of a chunk are zero from here on
     int sub_flip = 0;

@@ -127,6 +127,9 @@ public:
                         int* h_nout, DecimState* d_states = nullptr);
     int decimate_stream(DecimState* h_state, const uint8_t* iq, size_t nbytes, float* I, float* Q, uint32_t fill,
                         uint32_t cap, uint32_t* new_fill);
+    // one chunk of EACH of n receivers' streams (all of nbytes): one transfer and one launch set for all of them
+    int decimate_stream_many(DecimState* const* h_states, const uint8_t* const* iq, size_t nbytes, int n, float* const* I,
+                             float* const* Q, const uint32_t* fill, uint32_t cap, uint32_t* new_fill);
 
     struct Impl;
     struct DecodeRun;               // state of one decode_core() call (wspr_pipeline.hip)

@@ -750,3 +750,65 @@ def test_release_buffers_waits_for_calls_in_flight(env):
     for t in threads:
         t.join()
     assert not bad and freed > 0
+
+
+@pytest.mark.gpu
+def test_callbacks_of_many_receivers_fed_together(env):
+    """wspr_session_feed_many(): one callback of each of n receivers as one transfer and one launch set.  Five receivers
+    with different bytes, 260 callbacks each (the last ones 4 096 bytes long, as at a slot's end), one of them already
+    part-way into its buffer through single feeds: every buffer holds exactly the oracle's stream for its bytes, the
+    fills agree, duplicates and ragged lengths are refused."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_feed_many.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.wspr_session_fill.argtypes = [C.c_void_p, C.c_int]
+    L.wspr_session_fill.restype = C.c_uint32
+    L.wspr_session_samples.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.wspr_session_samples.restype = C.POINTER(C.c_float)
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    CB, NCB, NR, LEAD = 65536, 260, 5, 7
+    O = ol.lib()
+    rng = np.random.default_rng(4242)
+    streams = [rng.integers(0, 256, CB * (NCB - 2) + 2 * 4096 + (LEAD * CB if k == 2 else 0), dtype=np.uint8) for k in range(NR)]
+    want = []
+    for host in streams:
+        ost = O.orc_decim_new()
+        oi, oq = np.zeros(NS, np.float32), np.zeros(NS, np.float32)
+        nout, pos = 0, 0
+        sizes = ([CB] * LEAD if host.size > CB * (NCB - 2) + 2 * 4096 else []) + [CB] * (NCB - 2) + [4096, 4096]
+        for sz in sizes:                                       # the oracle, callback by callback like the receivers
+            chunk = np.ascontiguousarray(host[pos:pos + sz])
+            nout = O.orc_decim_feed(C.c_void_p(ost), ol.ptr(chunk), sz, ol.ptr(oi), ol.ptr(oq), nout, NS)
+            pos += sz
+        O.orc_decim_free(C.c_void_p(ost))
+        want.append((nout, oi, oq))
+    sessions = [L.wspr_session_create(w.default_options()) for _ in range(NR)]
+    offs = [0] * NR
+    for _ in range(LEAD):                                      # receiver 2 has been running for a while
+        chunk = np.ascontiguousarray(streams[2][offs[2]:offs[2] + CB])
+        assert L.wspr_session_feed(sessions[2], ol.ptr(chunk), CB) >= 0
+        offs[2] += CB
+    arr = (C.c_void_p * NR)(*sessions)
+    fills = (C.c_int * NR)()
+    for c in range(NCB):
+        sz = CB if c < NCB - 2 else 4096
+        chunks = [np.ascontiguousarray(streams[k][offs[k]:offs[k] + sz]) for k in range(NR)]
+        ptrs = (C.c_void_p * NR)(*[ch.ctypes.data for ch in chunks])
+        assert L.wspr_session_feed_many(arr, ptrs, sz, NR, fills) == 0
+        for k in range(NR):
+            offs[k] += sz
+    for k, s in enumerate(sessions):
+        nout, oi, oq = want[k]
+        assert fills[k] == nout == L.wspr_session_fill(s, 0), k
+        gi = np.ctypeslib.as_array(L.wspr_session_samples(s, 0, 0), shape=(NS,))
+        gq = np.ctypeslib.as_array(L.wspr_session_samples(s, 0, 1), shape=(NS,))
+        assert np.array_equal(gi[:nout], oi[:nout]) and np.array_equal(gq[:nout], oq[:nout]), k
+    twice = (C.c_void_p * 2)(sessions[0], sessions[0])
+    two = (C.c_void_p * 2)(chunks[0].ctypes.data, chunks[1].ctypes.data)
+    assert L.wspr_session_feed_many(twice, two, 4096, 2, None) == -1           # the same receiver twice
+    assert L.wspr_session_feed_many(arr, ptrs, 4100, NR, None) == -1           # not a multiple of 16
+    for s in sessions:
+        L.wspr_session_destroy(s)
