@@ -217,6 +217,15 @@ static void gpu_part(int nseg) {
                 for (int c = 0; c < 150; ++c) CHECK(wspr_session_feed(rx[k], raw.data(), (uint32_t)raw.size()) >= 0);
             });
         for (auto& t : th) t.join();
+        {                                           // ... and ten callbacks of all three at once
+            std::vector<uint8_t> raw(3 * 65536);
+            std::mt19937 rng(77);
+            for (auto& b : raw) b = (uint8_t)(120 + rng() % 16);
+            const uint8_t* ptrs[3] = {raw.data(), raw.data() + 65536, raw.data() + 2 * 65536};
+            int fills[3];
+            for (int c = 0; c < 10; ++c) CHECK(wspr_session_feed_many(rx, ptrs, 65536, 3, fills) == 0);
+            CHECK(fills[0] == fills[1] && fills[1] == fills[2]);
+        }
         int bufs[3], nres[3], flags[3];
         for (int k = 0; k < 3; ++k) bufs[k] = wspr_session_rollover(rx[k]);
         std::vector<decoder_results> d(3 * 8);
