@@ -35,6 +35,7 @@ namespace {
 // loudly on stderr and return a negative code; there is no CPU fallback.
 int fail(const char* where, const std::exception& e) {
     fprintf(stderr, "libwspr_mi355x: %s failed: %s\n", where, e.what());
+    (void)hipGetLastError();          // the runtime's sticky error belongs to THIS call: the next one starts clean
     return -1;
 }
 #ifdef WSPR_LAB

@@ -75,6 +75,7 @@ struct DevBuf {
         if (bytes > cap) {
             if (p) HIP_OK(hipFree(p));
             p = nullptr;
+            cap = 0;                                   // an allocation that fails leaves an EMPTY buffer behind, not a stale size
             size_t want = bytes + bytes / 4;
             HIP_OK(hipMalloc(&p, want));
             cap = want;
@@ -97,6 +98,7 @@ struct PinBuf {
         if (bytes > cap) {
             if (p) HIP_OK(hipHostFree(p));
             p = nullptr;
+            cap = 0;
             size_t want = bytes + bytes / 4;
             HIP_OK(hipHostMalloc(&p, want, hipHostMallocDefault));
             cap = want;

@@ -812,3 +812,30 @@ def test_callbacks_of_many_receivers_fed_together(env):
     assert L.wspr_session_feed_many(arr, ptrs, 4100, NR, None) == -1           # not a multiple of 16
     for s in sessions:
         L.wspr_session_destroy(s)
+
+
+@pytest.mark.gpu
+def test_a_batch_too_large_for_the_device_fails_cleanly_and_the_next_call_works(env):
+    """Thirty million segments cannot be held (5.4 TB of working rows): the very first allocation fails, the call returns
+    -1 with every n_results zero and nothing launched -- and the context is usable afterwards (a failed allocation used to
+    leave a buffer that remembered its old size with no memory behind it)."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_set_thread_slots(1)
+    K, nseg = 8, 48
+    I, Q, _ = bench.synth_batch_gpu(nseg, 31, dev, 1, -16.0, -16.0, 0.5)
+    torch.cuda.synchronize()
+    out = (w.decoder_results * (nseg * K))()
+    n = (C.c_int * nseg)()
+    opt = w.default_options()
+    assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), opt, C.addressof(out), K, C.addressof(n)) == 0
+    good = [[bytes(out[s * K + i].message) for i in range(n[s])] for s in range(nseg)]
+    assert sum(len(g) for g in good) >= nseg - 2
+    huge = 30_000_000
+    nh = np.ones(huge, np.int32)
+    assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), huge, NS, I.stride(0), opt, C.addressof(out), K, ol.ptr(nh)) == -1
+    assert not nh.any()
+    for _ in range(2):
+        assert L.wspr_decode_batch_device(I.data_ptr(), Q.data_ptr(), nseg, NS, I.stride(0), opt, C.addressof(out), K, C.addressof(n)) == 0
+        assert [[bytes(out[s * K + i].message) for i in range(n[s])] for s in range(nseg)] == good
+    L.wspr_set_thread_slots(0)
