@@ -87,7 +87,18 @@ def decode_from_root(I, Q, nseg_total, samples, options, decode_shard, max_resul
     and the spot records come back to `root` in global segment order (gather_spots_sharded)."""
     options = broadcast_options(options, src=root)
     mi, mq = scatter_segments(I, Q, nseg_total, samples, src=root)
-    out, cnt = decode_shard(mi, mq, options)
+    # a rank whose decode fails must not leave the others waiting in the gather: the outcome is exchanged first and every
+    # rank raises (the product returns -1 / raises when its GPU has gone; there is no CPU fallback to hide it)
+    err, out, cnt = None, None, None
+    try:
+        out, cnt = decode_shard(mi, mq, options)
+    except Exception as e:                                        # noqa: BLE001 -- reported on every rank below
+        err = "rank %d: %r" % (dist.get_rank(), e)
+    errors = [None] * dist.get_world_size()
+    dist.all_gather_object(errors, err)
+    errors = [e for e in errors if e]
+    if errors:
+        raise RuntimeError("decode_from_root: a shard failed (%s)" % "; ".join(errors))
     return gather_spots_sharded(out, cnt, nseg_total, max_results, record_size, dst=root)
 
 
@@ -110,23 +121,39 @@ def hashed_rounds(decode_shard, commit=None):
     Returns the number of rounds."""
     world, rank = dist.get_world_size(), dist.get_rank()
     empty = np.zeros((0, HASH_OP_BYTES), np.uint8)
-    stores = np.ascontiguousarray(decode_shard(empty, False), dtype=np.uint8).reshape(-1, HASH_OP_BYTES)
+
+    def attempt(prior, revisit):
+        # a rank whose decode fails must still reach the exchanges below, or the others wait for it for ever: the failure
+        # travels with the exchange and EVERY rank raises
+        try:
+            return np.ascontiguousarray(decode_shard(prior, revisit), dtype=np.uint8).reshape(-1, HASH_OP_BYTES), None
+        except Exception as e:                                    # noqa: BLE001 -- reported on every rank below
+            return empty, "rank %d: %r" % (rank, e)
+
+    def raise_if_any(errors):
+        errors = [e for e in errors if e]
+        if errors:
+            raise RuntimeError("hashed_rounds: a shard failed (%s)" % "; ".join(errors))
+    stores, err = attempt(empty, False)
     seen = empty.tobytes()
     rounds = 1
     while True:
         every = [None] * world
-        dist.all_gather_object(every, stores.tobytes())
+        dist.all_gather_object(every, (err, stores.tobytes()))
+        raise_if_any([e for e, _ in every])
+        every = [b for _, b in every]
         prior_bytes = b"".join(every[:rank])
         changed = False
         if prior_bytes != seen:
             prior = np.frombuffer(prior_bytes, np.uint8).reshape(-1, HASH_OP_BYTES)
-            new = np.ascontiguousarray(decode_shard(prior, True), dtype=np.uint8).reshape(-1, HASH_OP_BYTES)
+            new, err = attempt(prior, True)
             seen = prior_bytes
             changed = new.tobytes() != stores.tobytes()
             stores = new
         flags = [None] * world
-        dist.all_gather_object(flags, changed)
-        if not any(flags):
+        dist.all_gather_object(flags, (err, changed))
+        raise_if_any([e for e, _ in flags])
+        if not any(c for _, c in flags):
             break
         rounds += 1
         if rounds > world + 1:

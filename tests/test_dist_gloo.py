@@ -293,6 +293,43 @@ def test_world3_hashed_rounds_reach_the_serial_result():
     assert every[0][2] == [False] and all(r[1] <= 4 for r in every)
 
 
+def _hr_fail_worker(rank, world, port, q, when):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_wsprd_amd import dist as wd
+
+    def decode_shard(prior, revisit):
+        if rank == 1 and revisit == when:
+            raise RuntimeError("the GPU of rank 1 has gone")
+        return np.stack([_op(rank, 1 + rank, 2, "R%d" % rank)])   # every rank stores something: rank 1 and 2 must revisit
+    try:
+        wd.hashed_rounds(decode_shard, lambda allst: q.put(("committed", rank)))
+        q.put(("returned", rank))
+    except RuntimeError as e:
+        q.put(("raised", rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("when", [False, True])
+def test_world3_hashed_rounds_a_failing_shard_stops_every_rank(when):
+    """A rank whose decode fails (first round or a revisit) used to leave hashed_rounds() and the others waited in the
+    exchange for ever; now the failure travels with the exchange: every rank raises, nothing is committed, nobody hangs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + (7 if when else 0)
+    procs = [ctx.Process(target=_hr_fail_worker, args=(r, 3, port, q, when)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == ["raised"] * 3 and sorted(g[1] for g in got) == [0, 1, 2]
+    assert all("rank 1" in g[2] and "has gone" in g[2] for g in got)
+
+
 def _hs_worker(rank, world, port, q, workdir):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -373,6 +410,43 @@ def _root_worker(rank, world, port, q, product, nseg):
         assert res is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _root_fail_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rtlsdr_wsprd_amd as w
+    from rtlsdr_wsprd_amd import dist as wd
+    I = Q = torch.zeros(4, 45000) if rank == 0 else None
+
+    def decode_shard(mi, mq, o):
+        if rank == 1:
+            raise RuntimeError("no usable HIP device")
+        n = mi.shape[0]
+        return (w.decoder_results * (n * K))(), (C.c_int * n)()
+    try:
+        wd.decode_from_root(I, Q, 4, 45000, w.default_options(), decode_shard, max_results=K, record_size=80, root=0)
+        q.put(("returned", rank))
+    except RuntimeError as e:
+        q.put(("raised", rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_a_failing_shard_stops_every_rank_of_decode_from_root():
+    """Rank 1's decode fails (no GPU, say): both ranks raise instead of rank 0 waiting in the gather for ever."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_root_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == ["raised", "raised"] and all("rank 1" in g[2] for g in got)
 
 
 def _run_root_scatter(product, world=2, nseg=5):
