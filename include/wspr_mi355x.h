@@ -346,7 +346,7 @@ unsigned wspr_set_fano_fast_budget(unsigned cycles_per_bit);
 /* Where a batch's Fano attempts run: 0 = the host pool (the north star's partition; with the budget split
  * above if set), 1 = every attempt on the device (the exact wave-parallel search, straight from the soft
  * symbols in HBM: no host Fano, nothing postponed or decoded twice), -1 = automatic (default; env
- * WSPR_FANO_DEVICE): the device for batches of >= 256 segments per pipeline when the rank has fewer than four
+ * WSPR_FANO_DEVICE): the device for batches of >= 32 segments per pipeline when the rank has fewer than four
  * host threads or the pipeline's previous batch met more than one time-out per ten segments (a crowded band),
  * the host otherwise (single calls always).  Results are identical in every mode.  Returns the previous value. */
 int wspr_set_fano_device_mode(int mode);

@@ -216,17 +216,19 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     CpuSpan cpu_all(&c.t_ms[16]);
-    t_spin_us = nseg <= 16 ? 600 : 40;
+    t_spin_us = nseg <= 128 ? 600 : 40;      // a call of up to a hundred segments is a few milliseconds: its waits poll (lone 17-127-segment calls: 1.7-2.8 -> 1.3-2.3 ms)
     for (int s = 0; s < nseg; ++s) n_results[s] = 0;
     const int blocks = 4 * (samples / kFftSize) - 1;
     if (nseg <= 0) return 0;
     if (samples > kMaxSamples || blocks < 23) return 0;      // outside what the reference arrays allow
 
     const unsigned fast_cfg = fano_fast_budget().load();
-    // small batches gain nothing from the split (their time-outs fit the host pool) and would pay
-    // the device kernel's latency
+    // A handful of segments gain nothing from the device search (their time-outs fit the host pool) and would pay its
+    // kernel's latency: 1 segment 3.0 against 3.9 ms, 4-17 segments alike.  From about 32 crowded segments on the host
+    // pool is what a lone call waits for (tools/lone_call_latency.py, 10 signals per segment, 16 CPUs: 64 segments 76
+    // against 32 ms, 127: 153 against 34, 256: 116 against 38; the limit was 256 until the end of round 5).
     const bool dev_fano = fano_device_mode() > 0 ||
-                          (fano_device_mode() < 0 && nseg >= 256 && (rank_cpus() < 4 || d->crowded));
+                          (fano_device_mode() < 0 && nseg >= 32 && (rank_cpus() < 4 || d->crowded));
     // a traced decode runs every attempt with the full budget where it is first met (nothing provisional)
     // (a shared hash memory keeps the host's full budget too: a provisional failure would log look-ups of a decode
     // that is thrown away)
