@@ -260,10 +260,12 @@ static inline void copy_row_streaming(float* __restrict__ dst, const float* __re
 }
 
 // The reference's callers hand wspr_decode() HOST buffers (rtlsdr_wsprd.c:316, :689).  Pinned caller memory goes to
-// the device as one asynchronous strided copy per rail (DMA at the link's rate, no host work).  Pageable caller memory
-// would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows are gathered
-// (host pool) into this context's two pinned chunks, already in the working layout, and each chunk leaves as ONE
-// contiguous asynchronous copy per rail while the pool fills the other chunk.
+// the device as LINEAR asynchronous copies of up to 256 rows (DMA at the link's rate, no host work) into a dense
+// buffer that a row kernel on a stream of its own spreads into the working layout under the next copy.  Pageable
+// caller memory would make the runtime stage it through its own small bounce buffers, synchronously; instead the rows
+// are gathered (host pool) into this context's two pinned chunks, already in the working layout, and each chunk leaves
+// as ONE contiguous asynchronous copy per rail while the pool fills the other chunk.  A call of fewer than sixteen
+// segments (a receiver's own record) does not queue at the link's turnstile (pageable: the runtime's own strided copy).
 void Context::load_host(const float* I, const float* Q, int nseg, int samples, size_t stride) {
     Impl& c = *d;
     float* wi = work_i(nseg);
