@@ -107,7 +107,7 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
 RAW_BYTES = 576_000_000                      # 120 s x 2.4 Msps x 2 bytes
 
 
-def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0, amp_lsb=None):
+def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0, amp_lsb=None, messages=None):
     """Config-5 raw segments: unsigned 8-bit interleaved I/Q at 2.4 Msps.  The config-2 baseband
     frame (375 sps) is held for 6400 samples, moved to -600 kHz (the tuner sits fs/4 above the band:
     rtlsdr_wsprd.c:1112; the receiver's (1, j, -1, -j) mixer brings it back), buried in wide-band
@@ -126,6 +126,8 @@ def synth_raw_gpu(nseg, seed, dev, snr_db=-20.0, noise_lsb=10.0, amp_lsb=None):
     chunk = 6400 * 1500                                   # 9.6 M samples per chunk
     for s in range(nseg):
         msg = synth.message_for(int(rng.integers(0, 1 << 20)))
+        if messages is not None:                            # the caller's texts (any type) instead of the drawn type-1 ones
+            msg = messages[s]
         sym = w.get_wspr_channel_symbols(msg)[1].astype(np.float64)
         f0 = rng.uniform(-100.0, 100.0)
         t0 = 2.0 + rng.uniform(-1.0, 1.0)

@@ -111,7 +111,9 @@ int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t se
  * hashtable.txt as nseg reference calls in index order.  This entry adds what a job sharded over several processes /
  * GPUs needs: the call's segments are global indices seg_index0 .. seg_index0 + nseg - 1, `prior` holds the stores of
  * the other shards (any order; those of earlier segments take part), and the call's own stores come back in
- * stores_out[0 .. *n_stores) (segment order; -3 if cap is too small).  *n_redecoded: segments decoded more than once.
+ * stores_out[0 .. *n_stores) (segment order).  cap too small: -3 with *n_stores = the capacity needed, nothing written to
+ * hashtable.txt, the result arrays filled; the same call again with WSPR_HASH_REVISIT, the same prior and a buffer of
+ * that size completes it (nothing is decoded twice).  *n_redecoded: segments decoded more than once.
  * Protocol for R shards (rtlsdr-wsprd_amd/dist.py decode_hashed_sharded): every shard calls with no prior and
  * WSPR_HASH_KEEP_FILE; the stores are exchanged; a shard whose predecessors' stores changed calls again with
  * WSPR_HASH_REVISIT (same buffers and result arrays: only the affected segments are decoded again); when no store list
@@ -244,7 +246,9 @@ int wspr_session_decode(wspr_session *s, int buffer, struct decoder_results *dec
  * batch call per distinct set of decoder options (the receivers of one band share theirs).  decodes: n rows of
  * max_results spots; n_results[k]; decoded[k] (optional) = 1 / 0 as wspr_session_decode() would have returned.  Spots
  * and what the buffers hold afterwards are those of wspr_session_decode() on each session in index order (with
- * usehashtable: the order of the hash memory).  Returns the number of buffers decoded, negative on error. */
+ * usehashtable on any of them that is the order of the hash memory: then only RUNS of consecutive sessions with equal
+ * options share a batch call, so sessions with options A, B, A are decoded 0, 1, 2).  Returns the number of buffers
+ * decoded, negative on error. */
 int wspr_session_decode_many(wspr_session *const *sessions, const int *buffers, int n, struct decoder_results *decodes,
                              int max_results, int *n_results, int *decoded);
 uint32_t wspr_session_fill(const wspr_session *s, int buffer);

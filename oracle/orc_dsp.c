@@ -104,7 +104,8 @@ void orc_fft_bank(const float *idat, const float *qdat, int samples, float *ps) 
             xr[j] = idat[k] * win[j];
             xi[j] = qdat[k] * win[j];
         }
-        orc_fft512(xr, xi);
+        if (orc_get_fft_variant() == 0) orc_fft512(xr, xi);
+        else                            orc_fft512_variant(xr, xi);   /* robustness study only: orc_fft_alt.c */
         for (int j = 0; j < ORC_FFT; j++) {
             int k = (j + ORC_FFT / 2) & (ORC_FFT - 1);
             float a = xr[k] * xr[k], b = xi[k] * xi[k];

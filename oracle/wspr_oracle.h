@@ -119,6 +119,11 @@ extern unsigned char orc_sync_vector[ORC_NSYM];
 /* ---- DSP stages --------------------------------------------------------- */
 /* 512-point forward FFT, float32, radix-2 DIF, output in natural order. */
 void orc_fft512(float *re, float *im);
+/* Robustness study (orc_fft_alt.c): 0 = the FFT above (default, the product's arithmetic), 1 = float64 rounded to
+ * float32, 2..7 = other float32 factorisations.  Process-wide; set it before decoding, not while other threads decode. */
+int  orc_set_fft_variant(int variant);
+int  orc_get_fft_variant(void);
+void orc_fft512_variant(float *re, float *im);
 /* ps[bin*blocks + t], bin 0..511 (fft-shifted), t 0..blocks-1. */
 int  orc_blocks_for(int samples);
 void orc_fft_bank(const float *idat, const float *qdat, int samples, float *ps);

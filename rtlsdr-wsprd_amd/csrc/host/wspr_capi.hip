@@ -244,14 +244,15 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
     decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, writeback, idat, qdat, seg_stride,
                  nullptr, &hb, revisit ? &todo : nullptr,
                  ahead ? std::function<void()>([&] { ticket.wait_turn(); hb.load_file(); }) : std::function<void()>());
-    if (!(flags & WSPR_HASH_KEEP_FILE)) hb.commit_file();
     const std::vector<wspr::HashOp> st = hb.stores();
     if (n_stores) *n_stores = (int)st.size();
     if (n_redecoded) *n_redecoded = hb.redecoded;
-    if (stores_out) {
-        if ((int)st.size() > cap) return -3;
-        memcpy(stores_out, st.data(), st.size() * sizeof(wspr::HashOp));
-    }
+    // a store buffer that is too small fails the call BEFORE anything is committed: hashtable.txt is untouched, the
+    // result arrays hold the decode, *n_stores the capacity needed, and the same call with WSPR_HASH_REVISIT (same
+    // prior, a larger buffer) completes it without decoding anything again
+    if (stores_out && (int)st.size() > cap) return -3;
+    if (!(flags & WSPR_HASH_KEEP_FILE)) hb.commit_file();
+    if (stores_out && !st.empty()) memcpy(stores_out, st.data(), st.size() * sizeof(wspr::HashOp));
     return 0;
 }
 }  // namespace
@@ -1069,7 +1070,8 @@ int wspr_session_decode(wspr_session* s, int buffer, struct decoder_results* dec
 // (rtlsdr_wsprd.c:263-328) for every receiver of a service in one batch call per distinct set of decoder options
 // (receivers of one band share theirs; `freq` enters the reported frequency in double precision, so receivers with
 // different options are not folded into one call).  Results, and what the buffers hold afterwards, are those of
-// wspr_session_decode() on each session in index order -- with usehashtable that order is the order of the hash memory.
+// wspr_session_decode() on each session in index order -- with usehashtable that order is the order of the hash memory,
+// and only runs of consecutive sessions with equal options share a call (see `ordered` below).
 int wspr_session_decode_many(wspr_session* const* sessions, const int* buffers, int n, struct decoder_results* decodes,
                              int max_results, int* n_results, int* decoded) {
     if (!sessions || !buffers || n < 0 || !decodes || max_results < 1 || !n_results) return -1;
@@ -1085,12 +1087,20 @@ int wspr_session_decode_many(wspr_session* const* sessions, const int* buffers, 
     std::vector<float> I, Q;
     std::vector<decoder_results> out;
     std::vector<int> nout, group;
+    // the hash memory (hashtable.txt) is shared by every session with the option and ordered by the calls: as soon as one
+    // ready session uses it, only RUNS of consecutive sessions with equal options are folded, so that the memory sees
+    // the sessions in index order whatever their options (opt A, opt B, opt A stays 0, 1, 2 -- not 0, 2, 1)
+    bool ordered = false;
+    for (int k : ready) ordered = ordered || sessions[k]->opt.usehashtable != 0;
     for (size_t a = 0; a < ready.size(); ++a) {
         if (taken[a]) continue;
         const decoder_options& opt = sessions[ready[a]]->opt;
         group.clear();
-        for (size_t b = a; b < ready.size(); ++b)
-            if (!taken[b] && std::memcmp(&sessions[ready[b]]->opt, &opt, sizeof opt) == 0) { taken[b] = 1; group.push_back(ready[b]); }
+        for (size_t b = a; b < ready.size(); ++b) {
+            const bool same = !taken[b] && std::memcmp(&sessions[ready[b]]->opt, &opt, sizeof opt) == 0;
+            if (same) { taken[b] = 1; group.push_back(ready[b]); }
+            else if (ordered) break;
+        }
         const int m = (int)group.size();
         int rc;
         if (m == 1) {

@@ -164,7 +164,7 @@ def hashed_rounds(decode_shard, commit=None):
     return rounds
 
 
-def decode_batch_hashed_sharded(I, Q, nseg_total, options, max_results=16):
+def decode_batch_hashed_sharded(I, Q, nseg_total, options, max_results=16, store_cap=None):
     """The product under hashed_rounds(): this rank's shard_range() block of host rows I, Q ([n, samples] float32 numpy)
     through wspr_decode_batch_hashed().  Returns (decoder_results ctypes array [n * max_results], int32 counts [n],
     rounds).  Every rank must run in the same working directory as far as hashtable.txt is concerned only on rank 0
@@ -183,8 +183,10 @@ def decode_batch_hashed_sharded(I, Q, nseg_total, options, max_results=16):
     assert I.shape[0] == n and Q.shape == I.shape
     out = (w.decoder_results * (max(1, n) * max_results))()
     cnt = (C.c_int * max(1, n))()
-    cap = 64 * n + 64
-    buf = np.zeros((cap, HASH_OP_BYTES), np.uint8)
+    # every decode logs one or two stores; a shard that logs more than the buffer holds gets -3 and the size it needs
+    # (nothing committed, results in place), and the call is completed with WSPR_HASH_REVISIT and a buffer of that size
+    st = {"cap": (4 * n + 64) if store_cap is None else int(store_cap)}
+    st["buf"] = np.zeros((st["cap"], HASH_OP_BYTES), np.uint8)
     opt = type(options).from_buffer_copy(bytes(options))
     opt.usehashtable = 1
 
@@ -193,13 +195,20 @@ def decode_batch_hashed_sharded(I, Q, nseg_total, options, max_results=16):
             return np.zeros((0, HASH_OP_BYTES), np.uint8)
         pr = np.ascontiguousarray(prior)
         n_st = C.c_int(0)
-        rc = L.wspr_decode_batch_hashed(I.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), n, I.shape[1], I.shape[1], opt,
-                                        C.addressof(out), max_results, C.addressof(cnt), 0, lo,
-                                        pr.ctypes.data_as(C.c_void_p) if len(pr) else None, len(pr),
-                                        1 | (2 if revisit else 0), buf.ctypes.data_as(C.c_void_p), cap, C.byref(n_st), None)
+
+        def call(flags):
+            return L.wspr_decode_batch_hashed(I.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), n, I.shape[1], I.shape[1],
+                                              opt, C.addressof(out), max_results, C.addressof(cnt), 0, lo,
+                                              pr.ctypes.data_as(C.c_void_p) if len(pr) else None, len(pr), flags,
+                                              st["buf"].ctypes.data_as(C.c_void_p), st["cap"], C.byref(n_st), None)
+        rc = call(1 | (2 if revisit else 0))
+        if rc == -3 and n_st.value > st["cap"]:
+            st["cap"] = n_st.value + 64
+            st["buf"] = np.zeros((st["cap"], HASH_OP_BYTES), np.uint8)
+            rc = call(1 | 2)
         if rc != 0:
             raise RuntimeError("wspr_decode_batch_hashed failed (rc %d)" % rc)
-        return buf[:n_st.value].copy()
+        return st["buf"][:n_st.value].copy()
 
     def commit(all_stores):
         a = np.ascontiguousarray(all_stores)

@@ -330,7 +330,7 @@ def test_world3_hashed_rounds_a_failing_shard_stops_every_rank(when):
     assert all("rank 1" in g[2] and "has gone" in g[2] for g in got)
 
 
-def _hs_worker(rank, world, port, q, workdir):
+def _hs_worker(rank, world, port, q, workdir, store_cap=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.chdir(workdir)
@@ -340,7 +340,7 @@ def _hs_worker(rank, world, port, q, workdir):
     segs = _ht_segments()
     lo, hi = wd.shard_range(len(segs), rank, world)
     I = np.stack([segs[s][0] for s in range(lo, hi)]); Q = np.stack([segs[s][1] for s in range(lo, hi)])
-    out, cnt, rounds = wd.decode_batch_hashed_sharded(I, Q, len(segs), w.default_options(), max_results=8)
+    out, cnt, rounds = wd.decode_batch_hashed_sharded(I, Q, len(segs), w.default_options(), max_results=8, store_cap=store_cap)
     mine = [sorted(out[i * 8 + k].message.split(b"\0")[0].decode() for k in range(cnt[i])) for i in range(hi - lo)]
     allm = [None] * world
     dist.all_gather_object(allm, (mine, rounds))
@@ -351,15 +351,18 @@ def _hs_worker(rank, world, port, q, workdir):
 
 
 @pytest.mark.gpu
-def test_world2_hashtable_without_turns_through_the_product(tmp_path):
+@pytest.mark.parametrize("store_cap", [None, 1])
+def test_world2_hashtable_without_turns_through_the_product(tmp_path, store_cap):
     """decode_batch_hashed_sharded(): two gloo ranks decode their shards AT ONCE with usehashtable (no in_rank_order
-    turns); spots and hashtable.txt equal those of the oracle walking the four segments in order."""
+    turns); spots and hashtable.txt equal those of the oracle walking the four segments in order.  store_cap = 1: the
+    store buffer is too small on the first call of every round (-3 from the library, nothing committed) and the call is
+    completed with WSPR_HASH_REVISIT and the size the library asked for."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     shared = tmp_path / "ranks"; shared.mkdir()
     port = 35500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_hs_worker, args=(r, 2, port, q, str(shared))) for r in range(2)]
+    procs = [ctx.Process(target=_hs_worker, args=(r, 2, port, q, str(shared), store_cap)) for r in range(2)]
     for p in procs:
         p.start()
     got, rounds = q.get(timeout=300)

@@ -620,6 +620,75 @@ def test_many_receivers_one_slot_decoded_together(env):
 
 
 @pytest.mark.gpu
+def test_many_receivers_with_hashtable_keep_index_order_across_option_groups(env, tmp_path):
+    """Three receivers with usehashtable and options A, B, A: receiver 1 (the other band) sends the type-2 message whose
+    call receiver 2's type-3 "<call>" needs.  The hash memory must see the receivers in index order 0, 1, 2 -- as three
+    wspr_session_decode() calls would -- although 0 and 2 share their options (folding them into one batch call ahead of
+    receiver 1 would leave "<...>" in receiver 2's spot)."""
+    torch, bench, w, dev = env
+    L = w.lib()
+    L.wspr_session_create.restype = C.c_void_p
+    L.wspr_session_create.argtypes = [w.decoder_options]
+    L.wspr_session_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.wspr_session_rollover.argtypes = [C.c_void_p]
+    L.wspr_session_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_decode_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_session_destroy.argtypes = [C.c_void_p]
+    texts = ["K1JT FN20 20", "PJ4/K1ABC 37", "<PJ4/K1ABC> FK52UD 37"]
+    raw, _ = bench.synth_raw_gpu(3, 13579, dev, -12.0, messages=texts)
+    streams = [raw[k].cpu().numpy() for k in range(3)]
+    del raw
+    torch.cuda.empty_cache()
+    dials = [14095600, 7038600, 14095600]
+    K = 50
+
+    def receivers():
+        out = []
+        for host, dial in zip(streams, dials):
+            o = w.default_options(freq=dial)
+            o.usehashtable = 1
+            s = L.wspr_session_create(o)
+            for pos in range(0, host.size, 1 << 26):
+                chunk = np.ascontiguousarray(host[pos:pos + (1 << 26)])
+                assert L.wspr_session_feed(s, ol.ptr(chunk), chunk.size) >= 0
+            assert L.wspr_session_rollover(s) == 0
+            out.append(s)
+        return out
+
+    def in_dir(d, fn):
+        cwd = os.getcwd()
+        d.mkdir()
+        os.chdir(d)
+        try:
+            return fn(), open("hashtable.txt").read()
+        finally:
+            os.chdir(cwd)
+
+    def one_by_one():
+        got = []
+        for s in receivers():
+            res = (w.decoder_results * K)(); n = C.c_int(0)
+            assert L.wspr_session_decode(s, 0, res, C.byref(n)) == 1
+            got.append([bytes(res[i].message).split(b"\0")[0].decode() for i in range(n.value)])
+            L.wspr_session_destroy(s)
+        return got
+
+    def together():
+        ss = receivers()
+        arr = (C.c_void_p * 3)(*ss); bufs = (C.c_int * 3)(0, 0, 0)
+        res = (w.decoder_results * (3 * K))(); nres = (C.c_int * 3)()
+        assert L.wspr_session_decode_many(arr, bufs, 3, res, K, nres, None) == 3
+        got = [[bytes(res[k * K + i].message).split(b"\0")[0].decode() for i in range(nres[k])] for k in range(3)]
+        for s in ss:
+            L.wspr_session_destroy(s)
+        return got
+    want, wf = in_dir(tmp_path / "serial", one_by_one)
+    got, gf = in_dir(tmp_path / "many", together)
+    assert want[0] == ["K1JT FN20 20"] and want[1] == ["PJ4/K1ABC 37"] and want[2] == ["<PJ4/K1ABC> FK52UD 37"], want
+    assert got == want and gf == wf
+
+
+@pytest.mark.gpu
 def test_two_receivers_fed_from_two_threads(env):
     """A service has one RX thread per receiver (rtlsdr_wsprd.c:1136-1151 per dongle).  Every session's front end runs on
     the library's one reserved lane, so two threads feeding two sessions at once must take turns at it: each session's

@@ -238,3 +238,33 @@ def test_hashed_calls_in_flight_keep_their_order(w, tmp_path):
     assert strip(got) == strip(ref) and gf == rf
     print("calls in flight: %d of %d started before their predecessor had returned" % (overlap, nb - 1))
     assert overlap >= 1
+
+
+def test_store_buffer_too_small_commits_nothing_and_is_completed_by_a_revisit(w, tmp_path):
+    """cap smaller than the stores the call logs: -3, *n_stores = the size needed, hashtable.txt NOT written (the call
+    failed before its commit), results in place; the same call with WSPR_HASH_REVISIT and a buffer of that size returns
+    the stores and writes the file -- equal to the one-call form."""
+    nseg, K = 40, 16
+    I, Q, _ = _traffic(nseg, 0.3, 991)
+    whole, wf = _in_dir(tmp_path / "whole", lambda: [[_tup(x) for x in g] for g in w.wspr_decode_batch(I, Q, _opt(w, 1), max_results=K)])
+    L = w.lib()
+    L.wspr_decode_batch_hashed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+
+    def job():
+        out = (w.decoder_results * (nseg * K))(); nres = (C.c_int * nseg)()
+        small = np.zeros((2, 32), np.uint8); n_st = C.c_int(0)
+        rc = L.wspr_decode_batch_hashed(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, _opt(w, 1), C.addressof(out), K, C.addressof(nres), 0,
+                                        0, None, 0, 0, ol.ptr(small), 2, C.byref(n_st), None)
+        assert rc == -3 and n_st.value > 2
+        assert not os.path.exists("hashtable.txt")
+        first = [[_tup(out[s * K + i]) for i in range(nres[s])] for s in range(nseg)]
+        big = np.zeros((n_st.value, 32), np.uint8); n2 = C.c_int(0); n_re = C.c_int(-1)
+        rc = L.wspr_decode_batch_hashed(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, _opt(w, 1), C.addressof(out), K, C.addressof(nres), 0,
+                                        0, None, 0, 2, ol.ptr(big), n_st.value, C.byref(n2), C.byref(n_re))
+        assert rc == 0 and n2.value == n_st.value and n_re.value == 0
+        assert big[:, :4].view(np.int32).ravel().tolist() == sorted(big[:, :4].view(np.int32).ravel().tolist())
+        return first, [[_tup(out[s * K + i]) for i in range(nres[s])] for s in range(nseg)]
+    (first, second), f = _in_dir(tmp_path / "retry", job)
+    assert first == whole and second == whole and f == wf
