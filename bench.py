@@ -46,13 +46,17 @@ STAGE_BYTES = K1_BYTES + K23_BYTES           # 1 517 592 B per segment per pass
 HBM_PEAK_GBS = 8000.0
 
 
-def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_jitter=1.0, chunk=256, frac23=0.0):
+def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_jitter=1.0, chunk=256, frac23=0.0, wide=False):
     """Synthetic segments generated on the GPU (tests/synth.py is the numpy twin).
     n_signals = 1: SURVEY config 2 (f0 ~ U(-100,100) Hz, t0 = 2 s +- 1 s).
     n_signals > 1: config 3 (frequency slots across +-100 Hz, SNR linearly snr_hi..snr_lo, t0 +- 0.3 s).
     frac23 > 0: that share of the signals comes from compound-call stations alternating between their type-2 and
-    type-3 messages from segment to segment (-H traffic, synth.station_message)."""
+    type-3 messages from segment to segment (-H traffic, synth.station_message).
+    wide: every signal carries its own message out of the whole type-1 space (synth.message_wide) instead of one of the
+    7 600 combinations of synth.message_for -- what the timed batches use, so that no step finds its messages in a cache."""
     import synth
+    draw = (lambda r: synth.message_wide(int(r.integers(0, 1 << 62)))) if wide else \
+           (lambda r: synth.message_for(int(r.integers(0, 1 << 20))))
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -67,9 +71,9 @@ def synth_batch_gpu(nseg, seed, dev, n_signals=1, snr_hi=-20.0, snr_lo=-20.0, t_
         n = min(chunk, nseg - c0)
         if frac23 > 0.0:
             msgs = [[synth.station_message(int(rng.integers(0, 8)), c0 + r) if rng.random() < frac23
-                     else synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(n_signals)] for r in range(n)]
+                     else draw(rng) for _ in range(n_signals)] for r in range(n)]
         else:
-            msgs = [[synth.message_for(int(rng.integers(0, 1 << 20))) for _ in range(n_signals)] for _ in range(n)]
+            msgs = [[draw(rng) for _ in range(n_signals)] for _ in range(n)]
         for row in msgs:
             for m in row:
                 if m not in sym_cache:
@@ -349,7 +353,8 @@ def child_bench(args, config, steps, warmup, inflight=None, cpu_share=None, spaw
                                                              "OMP_NUM_THREADS")}
     cmd = [sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", str(steps), "--warmup", str(warmup),
            "--no-cpu-baseline", "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case",
-           "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-hashtable-block", "--no-kernel-roofline"]
+           "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-hashtable-block", "--no-kernel-roofline",
+           "--no-warm-extra", "--rotate", str(args.rotate)]
     if inflight:
         cmd += ["--inflight", str(inflight)]
     if cpu_share:
@@ -380,6 +385,8 @@ def slim(d):
             "host_pool_workers": d.get("host_pool_workers"), "decoded_ok": d["decoded_ok"],
             "false_decodes": d["false_decodes"], "gathered_over": d["config"]["gathered_over"],
             "gather_ms_per_step": d.get("gather_ms_per_step"), "gather_cpu_ms_per_step": d.get("gather_cpu_ms_per_step"),
+            "message_cache_hit_rate_last_step": d.get("stage_ms_last_step", {}).get("message_cache_hit_rate"),
+            "distinct_batches_rotated": d["config"].get("distinct_batches_rotated"),
             "child_wall_s": d["child_wall_s"]}
 
 
@@ -456,9 +463,9 @@ def host_entry_block(dev, lanes, resident):
     # host rows per variant keep the default command short)
     for name, nseg, nsig, steps, K in (("configs1", 1024, 1, 96, 16), ("configs2", 4096, 10, 12, 32)):
         if nsig == 1:
-            I, Q, _ = synth_batch_gpu(nseg, 1234, dev, 1, -20.0, -20.0, 1.0)
+            I, Q, _ = synth_batch_gpu(nseg, 1234, dev, 1, -20.0, -20.0, 1.0, wide=True)
         else:
-            I, Q, _ = synth_batch_gpu(nseg, 4321, dev, 10, -10.0, -28.0, 0.3)
+            I, Q, _ = synth_batch_gpu(nseg, 4321, dev, 10, -10.0, -28.0, 0.3, wide=True)
         torch.cuda.synchronize()
         Ih, Qh = I.cpu().numpy(), Q.cpu().numpy()
         outs = [((w.decoder_results * (nseg * K))(), (C.c_int * nseg)()) for _ in range(inflight)]
@@ -659,6 +666,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 --pmc passes (about 40 s); read it from profiles/")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
+    ap.add_argument("--rotate", type=int, default=3,
+                    help="distinct resident batches (other seeds, every signal its own message) a lane rotates through from step "
+                         "to step, so that no step finds the previous one's messages in the host's message cache; 1 = the "
+                         "round-5 shape (ONE batch of 7 600 possible messages decoded on every step: a warm cache)")
+    ap.add_argument("--no-warm-extra", action="store_true",
+                    help="skip the labelled extra 'warm_cache' (the round-5 shape measured beside the cold figure)")
     ap.add_argument("--fano-fast", type=int, default=None,
                     help="host Fano budget in cycles/bit before an attempt is left to the device tail (configs[2]; "
                          "default 200 with >= 8 CPUs per rank, 60 with 4-7, 25 below; 10000 = no split)")
@@ -761,19 +774,28 @@ def main():
 
     lanes_primary = inflight
 
-    def measure(config, nseg, steps, warmup, seed):
-        """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds)."""
+    def measure(config, nseg, steps, warmup, seed, warm=False):
+        """Builds the workload of one configuration and times `steps` steps of it (>= --min-seconds).
+        Cold by construction (round 6): --rotate distinct batches, every signal its own message; a lane's consecutive steps
+        decode different batches.  warm=True: ONE batch of synth.message_for texts on every step (the round-5 shape)."""
         fast_old = None
         inflight = lanes_primary if config == args.config else (min(args.inflight, 6) if args.inflight else default_inflight(config))
+        nrot = 1 if (config == 5 or warm) else max(1, args.rotate)
+        wide = nrot > 1
+        batches = []                                     # [(I, Q, expected)]: the distinct batches a lane rotates through
         if config in (2, 4):
-            I, Q, expected = synth_batch_gpu(nseg, 1234 + seed, dev, 1, args.snr, args.snr, 1.0)
+            for b in range(nrot):
+                batches.append(synth_batch_gpu(nseg, 1234 + seed + 7919 * b, dev, 1, args.snr, args.snr, 1.0, wide=wide))
+            I, Q, expected = batches[0]
             workload = "configs[1]: %d synthetic wsprsim segments per GPU, 1 signal each, SNR %g dB" % (nseg, args.snr)
             if config == 4:
                 workload = ("configs[3], one rank's shard: %d of the 65 536 single-signal segments (8 GPUs x 8 192; SURVEY 8d: "
                             "'config 4 ... as config 2'), SNR %g dB, generated with the rank's seed" % (nseg, args.snr))
             raw = None
         elif config == 3:
-            I, Q, expected = synth_batch_gpu(nseg, 4321 + seed, dev, 10, -10.0, -28.0, 0.3)
+            for b in range(nrot):
+                batches.append(synth_batch_gpu(nseg, 4321 + seed + 7919 * b, dev, 10, -10.0, -28.0, 0.3, wide=wide))
+            I, Q, expected = batches[0]
             workload = "configs[2]: %d segments per GPU x 10 overlapping signals, SNR -10..-28 dB, deep search on" % nseg
             raw = None
             if nseg >= 1024 and "WSPR_FANO_FAST" not in os.environ:
@@ -800,6 +822,10 @@ def main():
                         "through the on-GPU decimator (K0) in waves of %d into an IQ ring, decoded %d segments per decoder "
                         "call; 1 signal each, SNR %g dB, 10 LSB rms noise; the config's 4096 segments = %d such steps"
                         % (nraw, nraw, nseg, args.snr, max(1, 4096 // nseg)))
+        if config != 5:
+            workload += ("; %d distinct batches resident (seeds apart, every signal its own message out of the whole type-1 "
+                         "space), a lane's consecutive steps decode different ones" % nrot) if nrot > 1 else \
+                        "; ONE batch of 7 600 possible messages decoded on every step (warm message cache, the round-5 shape)"
         torch.cuda.synchronize()
         slots = args.slots if args.slots else (1 if inflight >= 4 else 0)         # few in flight: the library's own split
         slots_used = [ex.submit(L.wspr_set_thread_slots, slots).result() for ex in lanes][0]
@@ -809,7 +835,7 @@ def main():
             IQs = [(I, Q)] + [(torch.zeros_like(I), torch.zeros_like(Q)) for _ in range(inflight - 1)]
             torch.cuda.synchronize()                     # raw pointers from here on (stream contract of the library)
 
-        def decode_on(k):
+        def decode_on(k, b=0):
             if config == 5:
                 Ik, Qk = IQs[k]
                 row = Ik.stride(0) * 4
@@ -819,24 +845,25 @@ def main():
                     assert rc == 0
                 decs[k].decode_ptr(Ik.data_ptr(), Qk.data_ptr(), NS, Ik.stride(0))
             else:
-                decs[k].decode(I, Q)
-            return k, w.last_timings()                   # timings of THIS step, read on the lane that ran it
+                decs[k].decode(batches[b][0], batches[b][1])
+            return (k, b), w.last_timings()              # timings of THIS step, read on the lane that ran it
 
         gather_s = [0.0, 0, 0.0]                             # seconds in the fan-in (wall), gathers, CPU seconds of the driving thread
 
         def run_steps(n):
             """n steps, at most `inflight` of them running; spot records are gathered in step order."""
-            pending, last, tim, lastk = [], None, None, 0
+            pending, last, tim, lastk, lastb = [], None, None, 0, 0
             for s in range(n):
                 done = None
                 if len(pending) >= inflight:
-                    done, tim = pending.pop(0).result()
+                    (done, _), tim = pending.pop(0).result()
                     if use_dist:
                         t_g, c_g = time.perf_counter(), time.thread_time()
                         gatherers[done].stage()               # results copied out: the lane is free again
                         gather_s[0] += time.perf_counter() - t_g
                         gather_s[2] += time.thread_time() - c_g
-                pending.append(lanes[s % inflight].submit(decode_on, s % inflight))
+                # lane k = s mod inflight runs its j-th step (j = s div inflight) on batch (k + j) mod nrot
+                pending.append(lanes[s % inflight].submit(decode_on, s % inflight, (s % inflight + s // inflight) % nrot))
                 if done is not None and use_dist:
                     t_g, c_g = time.perf_counter(), time.thread_time()
                     last = gatherers[done].exchange()         # every rank's records land on rank 0 (RCCL)
@@ -844,14 +871,14 @@ def main():
                     gather_s[2] += time.thread_time() - c_g
                     gather_s[1] += 1
             for fut in pending:
-                lastk, tim = fut.result()
+                (lastk, lastb), tim = fut.result()
                 if use_dist:
                     t_g, c_g = time.perf_counter(), time.thread_time()
                     last = gatherers[lastk].gather()
                     gather_s[0] += time.perf_counter() - t_g
                     gather_s[2] += time.thread_time() - c_g
                     gather_s[1] += 1
-            return last, tim, lastk
+            return last, tim, (lastk, lastb)
 
         # a lane needs about four untimed steps before its contexts, buffers, host pools and the clocks are
         # settled (tools/pipelined_trace.py: steps 0-1 create the contexts, 2-6 still run 11-22 ms)
@@ -880,7 +907,10 @@ def main():
             n_timed = int(np.ceil(steps * args.min_seconds / max(elapsed, 1e-6) * 1.1))
             elapsed, (gathered, timings, lastk) = timed(n_timed)
         # correctness of what was timed: every segment's message must be the transmitted one
-        dec = decs[lastk]                                                        # the last step's results
+        lastk, lastb = lastk
+        dec = decs[lastk]                                                        # the last step's results ...
+        I, Q, expected = batches[lastb] if batches else (I, Q, expected)         # ... and the batch it decoded
+        del batches
         got = [[s.message.decode() for s in dec.spots(i)] for i in range(nseg)]
         n_sent = sum(len(e) for e in expected)
         n_ok = sum(len(set(expected[i]) & set(got[i])) for i in range(nseg))
@@ -892,7 +922,10 @@ def main():
                 "workload": workload, "steps": n_timed, "elapsed": elapsed, "first_try": first, "untimed": untimed, "slots": slots_used, "inflight": inflight,
                 "value": world * nseg * n_timed / elapsed, "ms_per_step": elapsed / n_timed * 1e3,
                 "decoded_ok": "%d/%d" % (n_ok, n_sent), "false_decodes": n_false, "spots_total": total_spots,
-                "timings": timings,
+                "spots_own": dec.total_spots(),
+                "timings": dict(timings, message_cache_hit_rate=(timings.get("message_cache_hits", 0.0) /
+                                                                  max(1.0, timings.get("message_cache_lookups", 0.0)))),
+                "rotate": nrot,
                 # the fan-in of the timed steps as the driving thread saw it (staging copy + H2D + gather + D2H on rank 0)
                 "gather_ms_per_step": (1e3 * gather_s[0] / gather_s[1]) if gather_s[1] else None,
                 "gather_cpu_ms_per_step": (1e3 * gather_s[2] / gather_s[1]) if gather_s[1] else None}
@@ -909,7 +942,32 @@ def main():
         t_prog = now
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
     lap("headline (synthesis, untimed and timed steps)")
+    warm_extra = None
+    if not args.no_warm_extra and args.config != 5 and args.rotate > 1:
+        # the round-5 shape beside the cold figure (labelled extra, never `value`): ONE batch of synth.message_for texts
+        # decoded on every step, so every message after the first step comes out of the host's per-thread cache
+        keep = {k: m[k] for k in ("I", "Q")}
+        mw = measure(args.config, nseg, max(4, args.steps // 2), args.warmup, rank, warm=True)
+        warm_extra = {"value": mw["value"], "unit": "segments/s", "ms_per_step": mw["ms_per_step"], "steps": mw["steps"],
+                      "seconds_timed": mw["elapsed"], "decoded_ok": mw["decoded_ok"], "false_decodes": mw["false_decodes"],
+                      "message_cache_hit_rate_last_step": mw["timings"]["message_cache_hit_rate"],
+                      "cpu_ms_books_last_step": mw["timings"].get("cpu_ms_books"),
+                      "note": "ONE batch (7 600 possible messages) decoded on every step: the host's per-thread message cache is "
+                              "warm after the first step -- what rounds 2-5 reported; `value` above is the cold figure"}
+        del mw
+        m.update(keep)
+        torch.cuda.empty_cache()
+        lap("warm_cache extra")
 
+    # what every rank of the job did, as rank 0 sees it: the block of the job's segments it owned (contiguous shards,
+    # segment index -> rank by shard_range), its CPU share and what its library added to the host's load
+    mine = {"rank": rank, "segments": list(wd.shard_range(world * nseg, rank, world)), "host_threads": int(os.environ["WSPR_HOST_THREADS"]),
+            "host_pool_workers": int(L.wspr_host_pool_workers()), "spots_last_step": int(m["spots_own"]),
+            "decoded_ok": m["decoded_ok"], "false_decodes": m["false_decodes"], "device": list(my_dev)}
+    ranks_info = [mine]
+    if use_dist:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     fanout = None
     if use_dist and args.config != 5:
         # ---- real-input fan-out, untimed (the reference's callers hold the IQ in ONE place,
@@ -1032,6 +1090,19 @@ def main():
                 LL.wspr_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(4 * n_copy), 1, 10, C.addressof(rd))
                 roof["measured_read_only_GBs"] = 4.0 * n_copy / (rd[0] * 1e-3) / 1e9
                 del src, dst
+        if roof is not None and m["timings"].get("candidates_refined") is not None:
+            # the step as a whole against the bound that really limits it: the prescribed arithmetic of the fine search and
+            # the subtraction (SURVEY 8d per-unit figures x the counts of the last timed step) over the step's wall time,
+            # against the no-FMA fp32 vector bound (separately rounded mul and add: half the FMA peak)
+            tm = m["timings"]
+            flop = tm["candidates_refined"] * (K4_FLOP + K41_FLOP) + tm.get("subtractions", 0.0) * K7_FLOP
+            tf = flop / (m["ms_per_step"] * 1e-3) / 1e12
+            roof["step"] = {"bound": "fp32 VALU, no FMA", "flop_per_step": flop, "achieved_TFs": tf, "peak_TFs": VALU_NOFMA_TF,
+                            "frac": tf / VALU_NOFMA_TF, "frac_of_fp32_vector_peak": tf / VALU_PEAK_TF,
+                            "counts": {"candidates_refined": tm["candidates_refined"], "subtractions": tm.get("subtractions")},
+                            "per_unit_flop": {"lag_scan": K4_FLOP, "freq_scan": K41_FLOP, "subtract": K7_FLOP},
+                            "note": "the roofline block above answers the metric's letter (the FFT+sync stage's dominant kernel, "
+                                    "HBM-bound, < 2 % of a configs[2] step); THIS is what bounds the step: vector issue"}
         lap("kernel-level roofline, PMC passes, ceilings")
         cpu = None
         if args.config == 5 and roof is not None:
@@ -1114,7 +1185,8 @@ def main():
                        "gathered_over": ("rccl" if backend == "nccl" else backend) if use_dist else "none (one process)",
                        "launched_by": "bench.py --gpus N (self-spawned ranks)" if os.environ.get("WSPR_BENCH_SPAWNED")
                        else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
-                       "batches_in_flight": inflight, "slots_per_batch": m["slots"], "untimed_steps": m["untimed"]},
+                       "batches_in_flight": inflight, "slots_per_batch": m["slots"], "untimed_steps": m["untimed"],
+                       "distinct_batches_rotated": m["rotate"]},
             "steps_requested": args.steps, "seconds_timed": m["elapsed"], "first_try": m["first_try"],
             "decoded_ok": m["decoded_ok"], "false_decodes": m["false_decodes"], "spots_total": m["spots_total"],
             "stage_ms_last_step": dict(m["timings"], note="times: maximum over the slots of the lane that ran the last "
@@ -1126,7 +1198,7 @@ def main():
             "host_pool_workers": int(L.wspr_host_pool_workers()),
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "tertiary": tertiary,
             "configs3_shard": shard, "host_entry": host_entry, "usehashtable_batch": hashtable,
-            "fanout_check": fanout,
+            "fanout_check": fanout, "ranks": ranks_info if use_dist else None,
         }
         if world == 1 and not use_dist and args.config == 3:
             if not args.no_reference_case:
@@ -1137,6 +1209,24 @@ def main():
                 out["per_rank_share_of_8"] = share_of_8_block(args, inflight)
         lap("reference case, per_rank_share_of_8")
         out["wall_seconds_by_block"] = walls
+        out["warm_cache"] = warm_extra
+        # the figures a reader of the END of this (long) line needs, last: the driver records the tail of stdout
+        out["summary"] = {
+            "value_segments_per_s": m["value"], "ms_per_step": m["ms_per_step"], "workload": "configs[%d]" % (args.config - 1),
+            "message_cache_hit_rate_last_step": m["timings"].get("message_cache_hit_rate"),
+            "warm_cache_value": warm_extra["value"] if warm_extra else None,
+            "roofline_frac_K1_hbm": roof["frac"] if roof else None,
+            "fft_sync_stage_frac_hbm": roof["fft_sync_stage"]["frac"] if roof else None,
+            "roofline_step_frac_no_fma": roof["step"]["frac"] if roof and "step" in roof else None,
+            "cpu_baseline_segments_per_s": cpu["value"] if cpu else None,
+            "secondary_configs1_value": secondary["value"] if secondary else None,
+            "tertiary_configs4_value": tertiary["value"] if tertiary else None,
+            "tertiary_K0_frac_hbm": (tertiary["front_end_K0"].get("frac") if tertiary and isinstance(tertiary.get("front_end_K0"), dict) else None),
+            "configs3_shard_full_host_value": (shard.get("full_host", {}).get("value") if isinstance(shard, dict) else None),
+            "configs3_shard_share_of_8_value": (shard.get("share_of_8", {}).get("value") if isinstance(shard, dict) else None),
+            "configs3_shard_share_of_8_over_full_host": (shard.get("share_of_8_over_full_host") if isinstance(shard, dict) else None),
+            "per_rank_share_of_8": (out.get("per_rank_share_of_8", {}) or {}).get("value"),
+        }
     line = json.dumps(out) if rank == 0 else None
     if use_dist:
         dist.barrier()

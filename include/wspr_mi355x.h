@@ -299,7 +299,9 @@ void subtract_signal2(float *id, float *qd, long np, float f0, int shift, float 
  * candidates whose result was consumed (the others: speculation cut by a subtraction), [15] subtractions;
  * then the CPU time (not wall time) the calling thread spent in the call, milliseconds: [16] all of it, by phase [17] pass
  * start (candidate lists, re-ranking), [18] wave building, [19] fine search + first rung (launches, lists, gates),
- * [20] ladder, [21] bookkeeping (unpack, re-encode, de-dup), [22] subtraction launches, [23] result hand-over.
+ * [20] ladder, [21] bookkeeping (unpack, re-encode, de-dup), [22] subtraction launches, [23] result hand-over;
+ * then [24] decoded messages looked up in the calling thread's message cache (what a 50-bit message unpacks and
+ * re-encodes to, computed once per thread and message) and [25] how many of them it answered.
  * Returns the number of values written (<= capacity). */
 int wspr_last_timings(double *ms, int capacity);
 /* Worker threads of the library's host pools alive in this process (the threads that call into the library are

@@ -258,11 +258,11 @@ class BatchDecoder:
 
 
 def last_timings():
-    ms = (C.c_double * 24)()
-    n = lib().wspr_last_timings(C.addressof(ms), 24)
+    ms = (C.c_double * 26)()
+    n = lib().wspr_last_timings(C.addressof(ms), 26)
     names = ["fft_sync_ms", "host_bookkeeping_ms", "device_fano_tail_ms", "demod_ms", "subtract_ms", "host_fano_ms",
              "total_ms", "fano_calls", "fano_timeouts", "fano_cycles", "candidates_refined", "gpu_waves",
              "fano_left_to_device", "segments_redecoded", "candidates_consumed", "subtractions",
              "cpu_ms_call", "cpu_ms_pass_start", "cpu_ms_build_wave", "cpu_ms_refine", "cpu_ms_ladder", "cpu_ms_books",
-             "cpu_ms_subtract", "cpu_ms_finish"]
+             "cpu_ms_subtract", "cpu_ms_finish", "message_cache_lookups", "message_cache_hits"]
     return {names[i]: ms[i] for i in range(n)}

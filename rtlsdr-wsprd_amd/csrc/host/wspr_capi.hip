@@ -690,14 +690,14 @@ int wspr_last_timings(double* ms, int capacity) {
     // the calling thread's LAST batch call ran on (a capped or small call uses fewer than Context::slots(); contexts
     // are never created here)
     try {
-        double acc[24] = {0};
-        int n = 24;
+        double acc[26] = {0};
+        int n = 26;
         const int used = std::max(1, Context::last_slots_used());
         for (int g = 0; g < used; ++g) {
             Context* c = Context::slot_if_exists(g);
             if (!c) continue;
-            double t[24] = {0};
-            n = c->last_timings(t, 24);
+            double t[26] = {0};
+            n = c->last_timings(t, 26);
             for (int i = 0; i < n; ++i) acc[i] = (i < 7) ? (t[i] > acc[i] ? t[i] : acc[i]) : acc[i] + t[i];
         }
         n = n < capacity ? n : capacity;

@@ -242,7 +242,7 @@ struct Context::Impl {
     // host-side per-segment callsign hash memory (reference: locals of wspr_decode)
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
-    double t_ms[24] = {0};           // stage times (ms), Fano statistics and host CPU time by phase of the last batch
+    double t_ms[26] = {0};           // stage times (ms), Fano statistics and host CPU time by phase of the last batch
     std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0};
     bool blocking = false;
     hipEvent_t ev_sync = nullptr;

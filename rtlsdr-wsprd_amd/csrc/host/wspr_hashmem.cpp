@@ -148,8 +148,10 @@ MessageCache::Handle MessageCache::unpack(const unsigned char* decdata, HashTabl
     uint64_t key = 0;
     for (int k = 0; k < 7; ++k) key = (key << 8) | decdata[k];   // the 50 message bits live in bytes 0..6 (unpack50)
     if (map_.size() > 20000) map_.clear();                       // a few MB per host thread at most
+    ++lookups;
     auto it = map_.find(key);
     if (it != map_.end()) {
+        ++hits;
         Entry& e = it->second;
         memcpy(call_loc_pow, e.clp, sizeof e.clp); memcpy(call, e.call, sizeof e.call); memcpy(loc, e.loc, sizeof e.loc);
         memcpy(pwr, e.pwr, sizeof e.pwr); memcpy(callsign, e.callsign, sizeof e.callsign);

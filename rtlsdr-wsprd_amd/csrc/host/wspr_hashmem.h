@@ -90,6 +90,7 @@ public:
     // get_wspr_channel_symbols(call_loc_pow, ...) of reference wsprsim_utils.c:163-316
     int symbols(Handle& h, const char* call_loc_pow, HashTable& tab, unsigned char* sym);
     size_t size() const { return map_.size(); }
+    unsigned long lookups = 0, hits = 0;             // unpack() calls of this thread and how many the map answered
 
 private:
     std::unordered_map<uint64_t, Entry> map_;

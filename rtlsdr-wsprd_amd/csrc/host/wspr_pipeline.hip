@@ -809,7 +809,9 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         HashTable& tab = hb ? static_cast<HashTable&>(*shared) : static_cast<HashTable&>(flat);
         // (what the bits unpack and re-encode to is computed once per host thread: MessageCache, wspr_hashmem.h)
         MessageCache& mc = MessageCache::of_this_thread();
+        const unsigned long mc_hits0 = mc.hits;
         MessageCache::Handle mh = mc.unpack(w.decdata, tab, call_loc_pow, call, loc, pwr, callsign);
+        c.t_ms[24] += 1.0; c.t_ms[25] += (double)(mc.hits - mc_hits0);     // message-cache look-ups and hits of this call
         const int noprint = mh.noprint;
         auto symbols_of = [&](unsigned char* sym) { return mc.symbols(mh, call_loc_pow, tab, sym); };
         if (opt.subtraction && ipass == 0 && !noprint) {
@@ -967,7 +969,7 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
 }
 
 int Context::last_timings(double* ms, int cap) {
-    const int n = std::min(cap, 24);
+    const int n = std::min(cap, 26);
     for (int i = 0; i < n; ++i) ms[i] = d->t_ms[i];
     return n;
 }

@@ -30,6 +30,34 @@ def message_for(idx):
                          POWERS[(idx // 7) % len(POWERS)])
 
 
+_L = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+
+
+def message_wide(idx):
+    """A type-1 message drawn from (nearly) the whole space a receiver can hear: 26^5 x 10 six-character calls with the
+    digit at index 2 and 26^4 x 10 + 26^3 x 10 shorter ones with the digit at index 1 (the two shapes pack_call takes
+    without overflow), 18 x 18 x 100 locators, 19 powers -- every signal of a benchmark batch a different
+    message, so that nothing host-side can be answered from a cache of earlier decodes.  idx: any non-negative integer."""
+    r = int(idx)
+    shape, r = r % 4, r // 4
+    if shape:                                           # "KA1ABC"
+        c = [_L[r % 26]]; r //= 26
+        c.append(_L[r % 26]); r //= 26
+        c.append(str(r % 10)); r //= 10
+        for _ in range(3):
+            c.append(_L[r % 26]); r //= 26
+    else:                                               # "K1AB", "K1ABC" (a type-1 call has four characters or more,
+        c = [_L[r % 26]]; r //= 26                      # wsprsim_utils.c:201)
+        c.append(str(r % 10)); r //= 10
+        n = 2 + r % 2; r //= 2
+        for _ in range(n):
+            c.append(_L[r % 26]); r //= 26
+    g = _L[r % 18]; r //= 18
+    g += _L[r % 18]; r //= 18
+    g += "%02d" % (r % 100); r //= 100
+    return "%s %s %d" % ("".join(c), g, POWERS[r % len(POWERS)])
+
+
 def expected_text(msg):
     """Decoder prints a type-1 power with two digits (wsprd_utils.c:259); type-2 / type-3 texts come back as sent (the
     hashed call resolved)."""

@@ -106,12 +106,21 @@ def _run_world2(product):
 _HT_MSGS = [["PJ4/K1ABC 37"], ["W1AW FN31 10"], ["<PJ4/K1ABC> FK52UD 37", "W1AW FN31 10"], ["<PJ4/K1ABC> FK52UD 37"]]
 
 
-def _ht_segments():
+def _ht_msgs18():
+    """Eighteen segments for eight ranks (shards of 3, 3, 2, 2, ...): every segment carries a plain type-1 signal and the
+    transmissions of two compound-call stations, which alternate between their type-2 and type-3 forms from segment to
+    segment -- a "<call>" resolves only through what an EARLIER segment (usually another rank's) stored."""
+    import synth
+    return [[synth.message_for(1000 + 37 * s), synth.station_message(s % 8, s), synth.station_message((s + 3) % 8, s)]
+            for s in range(18)]
+
+
+def _ht_segments(msgs_by_segment=None):
     import oracle_lib as ol
     import synth
     symf = lambda m: ol.channel_symbols(m)[1]
     segs = []
-    for k, msgs in enumerate(_HT_MSGS):
+    for k, msgs in enumerate(_HT_MSGS if msgs_by_segment is None else msgs_by_segment):
         rng = np.random.default_rng(7100 + k)
         sigma = np.sqrt((375.0 / 2500.0) / 2.0)
         I = rng.normal(0, sigma, synth.NS); Q = rng.normal(0, sigma, synth.NS)
@@ -262,14 +271,16 @@ def _hr_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world3_hashed_rounds_reach_the_serial_result():
-    """hashed_rounds() on CPU with a toy decoder whose behaviour depends on its look-ups: three gloo ranks, everybody
+@pytest.mark.parametrize("world", [3, 8])
+def test_world3_hashed_rounds_reach_the_serial_result(world):
+    """hashed_rounds() on CPU with a toy decoder whose behaviour depends on its look-ups: three gloo ranks (and eight: the
+    size of the node configs[3] is quoted on -- nine segments over eight ranks, shards of one or two), everybody
     decodes at once, the stores are exchanged until they stop changing -- outputs and the committed store list are
     those of one process walking the segments in order; rank 0 never revisits, nobody needs more than world + 1 rounds."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_hr_worker, args=(r, 3, port, q)) for r in range(3)]
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_hr_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     every, committed = q.get(timeout=120)
@@ -290,7 +301,7 @@ def test_world3_hashed_rounds_reach_the_serial_result():
     assert got == want
     assert committed == want_stores
     assert want[4] == ["ZZ"] and want[6] == ["ZZ", "QQ"] and want[7] == ["CC"]      # resolved across rank boundaries
-    assert every[0][2] == [False] and all(r[1] <= 4 for r in every)
+    assert every[0][2] == [False] and all(r[1] <= world + 1 for r in every)
 
 
 def _hr_fail_worker(rank, world, port, q, when):
@@ -330,14 +341,14 @@ def test_world3_hashed_rounds_a_failing_shard_stops_every_rank(when):
     assert all("rank 1" in g[2] and "has gone" in g[2] for g in got)
 
 
-def _hs_worker(rank, world, port, q, workdir, store_cap=None):
+def _hs_worker(rank, world, port, q, workdir, store_cap=None, eighteen=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.chdir(workdir)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import rtlsdr_wsprd_amd as w
     from rtlsdr_wsprd_amd import dist as wd
-    segs = _ht_segments()
+    segs = _ht_segments(_ht_msgs18() if eighteen else None)
     lo, hi = wd.shard_range(len(segs), rank, world)
     I = np.stack([segs[s][0] for s in range(lo, hi)]); Q = np.stack([segs[s][1] for s in range(lo, hi)])
     out, cnt, rounds = wd.decode_batch_hashed_sharded(I, Q, len(segs), w.default_options(), max_results=8, store_cap=store_cap)
@@ -381,6 +392,38 @@ def test_world2_hashtable_without_turns_through_the_product(tmp_path, store_cap)
     # (rank 1 revisits once it has seen rank 0's stores; its own stores do not change -- a type-3 decode stores nothing --
     # so the exchange may already be over after the first round)
     assert got[3] == ["<PJ4/K1ABC> FK52UD 37"] and all(1 <= r <= 3 for r in rounds)
+
+
+@pytest.mark.gpu
+def test_world8_hashtable_without_turns_through_the_product(tmp_path):
+    """The same at the world size configs[3] is quoted on: EIGHT gloo ranks (sharing the one GPU of this box) decode their
+    shards of eighteen segments at once with usehashtable; spots and hashtable.txt equal those of the oracle walking the
+    eighteen segments in order, and type-3 calls resolve across rank boundaries."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shared = tmp_path / "ranks"; shared.mkdir()
+    port = 36500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_hs_worker, args=(r, 8, port, q, str(shared), None, True)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got, rounds = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    alone = tmp_path / "alone"; alone.mkdir()
+    cwd = os.getcwd()
+    segs = _ht_segments(_ht_msgs18())
+    try:
+        os.chdir(alone)
+        ref = _ht_decode(segs, 0, len(segs), False)
+        ref_file = open("hashtable.txt").read()
+    finally:
+        os.chdir(cwd)
+    assert got == ref and open(shared / "hashtable.txt").read() == ref_file
+    resolved = sum(m.startswith("<") and not m.startswith("<...>") for seg in got for m in seg)
+    print("world 8 -H: rounds per rank %r, %d resolved type-3 spots of %d spots" % (rounds, resolved, sum(len(g) for g in got)))
+    assert resolved >= 6 and len(rounds) == 8 and all(1 <= r <= 9 for r in rounds) and max(rounds) >= 2
 
 
 # ---- real-input fan-out: rank 0 holds the IQ, the other ranks receive their rows (SURVEY 8e) -----------------

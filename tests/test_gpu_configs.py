@@ -371,6 +371,39 @@ def test_bench_gpus_2_spawns_two_ranks_sharing_the_one_gpu():
     assert d["value"] > 0 and d["scaling"] == "weak"
 
 
+def test_bench_gpus_8_rehearsal_of_configs3_on_the_one_gpu():
+    """The 8-rank job configs[3] is quoted on, rehearsed on this 1-GPU box so that the first real 8-GPU run is not a
+    debugging session: `bench.py --gpus 8 --config 4 --segments 1024` -- eight self-spawned ranks (sharing the device,
+    collectives on gloo: RCCL refuses two ranks on one device), each with the CPU share of a rank of eight (2 host
+    threads) and its own shard.  Eight distinct contiguous shard ranges of shard_range(8 x 1024, r, 8) shape, no pool
+    thread on any rank, every rank's records gathered on rank 0, and rank 0's real input scattered to the seven others
+    and decoded there to the spots rank 0 gets itself."""
+    sys.path.insert(0, ROOT)
+    from rtlsdr_wsprd_amd import dist as wd
+    d = _bench_line(["--gpus", "8", "--config", "4", "--segments", "1024", "--steps", "6", "--warmup", "2", "--rotate", "2",
+                     "--no-cpu-baseline", "--no-warm-extra", "--no-kernel-roofline", "--min-seconds", "0", "--inflight", "4"],
+                    _no_launcher_env(WSPR_BENCH_SHARE_GPU="1", WSPR_BENCH_BACKEND="gloo", WSPR_HOST_THREADS="2"), timeout=1500)
+    assert d["n_gpus"] == 8 and d["distinct_devices"] == 1 and d["devices_shared"] is True and d["scaling"] == "weak"
+    ranks = d["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [tuple(r["segments"]) for r in ranks] == [wd.shard_range(8 * 1024, r, 8) for r in range(8)]
+    # (the same partition the full job uses: shard_range(65 536, r, 8) = 8 192-segment blocks, here at 1/8 of the size)
+    assert [wd.shard_range(65536, r, 8) for r in range(8)] == [(8192 * r, 8192 * (r + 1)) for r in range(8)]
+    assert [tuple(r["segments"]) for r in ranks] == [(1024 * r, 1024 * (r + 1)) for r in range(8)]
+    assert len({tuple(r["segments"]) for r in ranks}) == 8 and ranks[-1]["segments"][1] == 8 * 1024
+    assert all(r["host_threads"] == 2 and r["host_pool_workers"] == 0 for r in ranks), ranks
+    for r in ranks:
+        ok, sent = map(int, r["decoded_ok"].split("/"))
+        assert sent == 1024 and ok >= 0.95 * sent and r["false_decodes"] == 0 and r["spots_last_step"] >= ok
+    # the gathered records on rank 0 hold every rank's spots of the last step
+    assert d["spots_total"] == sum(r["spots_last_step"] for r in ranks)
+    f = d["fanout_check"]
+    assert f["segments_scattered_from_rank0"] == 32 and f["equal_to_rank0_own_decode"] == "32/32"
+    assert d["config"]["segments_per_gpu"] == 1024 and d["value"] > 0
+    print("8-rank rehearsal on one GPU: %.0f segments/s aggregate, %.1f ms per step, gather %.2f ms per step" % (
+        d["value"], d["ms_per_step"], d.get("gather_ms_per_step") or 0.0))
+
+
 # ------------------------------------------------------------------ receiver session (f4)
 def test_receiver_session_two_minute_flow(env):
     """The reference's receive loop through the session object: one full 2-minute raw segment arrives in
