@@ -168,7 +168,13 @@ int wspr_decode_batch_node(float *idat, float *qdat, int nseg, int samples, size
  * wspr_decimate_u8_batch_device() left there): every other device pulls its wspr_shard_range() block over xGMI
  * with a peer copy (the scatter of 360 000 B per segment for real inputs, here inside one process),
  * decodes it on its own host thread and writes its spots into the caller's arrays.  The stream contract of
- * wspr_decode_batch_device() applies to d_idat / d_qdat. */
+ * wspr_decode_batch_device() applies to d_idat / d_qdat.
+ * Failure semantics of both node-level calls: ndevices larger than the visible devices, or a source device that does not
+ * exist: -1 before anything runs.  Refused peer access is NOT a failure: the block then travels source device -> pinned
+ * host memory -> target device (a line on stderr says so).  A shard that fails (its device cannot be selected, its copy
+ * or its decode fails) fails the WHOLE call: the return value is negative and every n_results[] is 0 -- the other shards'
+ * spots are not reported, so that a caller never mistakes a partial result for the slot's spots; the call can be
+ * repeated (with fewer devices) as it stands, the inputs are untouched. */
 int wspr_decode_batch_node_device(const void *d_idat, const void *d_qdat, int src_device, int nseg, int samples,
                                   size_t seg_stride, struct decoder_options options,
                                   struct decoder_results *decodes, int max_results, int *n_results, int ndevices);

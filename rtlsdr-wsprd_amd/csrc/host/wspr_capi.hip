@@ -561,18 +561,50 @@ int wspr_decode_batch_node_device(const void* d_idat, const void* d_qdat, int sr
             const float *pi = si + off, *pq = sq + off;
             void *ti = nullptr, *tq = nullptr;
             // (under the test hook every block but the first takes the copy path, also on the source device itself)
+            // fault injection (lab build only): WSPR_NODE_FAIL_PEER=1 makes every peer copy report failure (the staged copy
+            // must take over), WSPR_NODE_FAIL_SHARD=k fails shard k outright (the whole call must fail, no spots reported)
+            const char* fail_peer = wspr::lab_env("WSPR_NODE_FAIL_PEER");
+            const char* fail_shard = wspr::lab_env("WSPR_NODE_FAIL_SHARD");
+            if (fail_shard && atoi(fail_shard) == k) {
+                fprintf(stderr, "libwspr_mi355x: shard %d (segments %d..%d, device %d) failed [injected]\n", k, lo, hi, dev);
+                rcs[k] = -1;
+                return;
+            }
             if (dev != src_device || (virt && atoi(virt) && k > 0)) {     // pull the block over xGMI
+                bool peer_ok = true;
                 if (dev != src_device) {
-                    (void)hipDeviceEnablePeerAccess(src_device, 0);      // "already enabled" is fine
+                    // refused peer access (no link, IOMMU policy, ...) is not an error: hipMemcpyPeer then goes through
+                    // the host by itself, and if it reports failure all the same the block is staged here explicitly
+                    const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_ok = false;
                     (void)hipGetLastError();
                 }
-                if (hipMalloc(&ti, floats * 4) != hipSuccess || hipMalloc(&tq, floats * 4) != hipSuccess ||
-                    hipMemcpyPeer(ti, dev, pi, src_device, floats * 4) != hipSuccess ||
-                    hipMemcpyPeer(tq, dev, pq, src_device, floats * 4) != hipSuccess ||
-                    // a device-to-device copy may return before it has run, and the library's streams are
-                    // non-blocking (they do not wait for the null stream): wait here
-                    hipStreamSynchronize(nullptr) != hipSuccess) {
-                    fprintf(stderr, "libwspr_mi355x: peer copy of segments %d..%d to device %d failed\n", lo, hi, dev);
+                bool ok = hipMalloc(&ti, floats * 4) == hipSuccess && hipMalloc(&tq, floats * 4) == hipSuccess;
+                bool copied = ok && !(fail_peer && atoi(fail_peer)) &&
+                              hipMemcpyPeer(ti, dev, pi, src_device, floats * 4) == hipSuccess &&
+                              hipMemcpyPeer(tq, dev, pq, src_device, floats * 4) == hipSuccess &&
+                              // a device-to-device copy may return before it has run, and the library's streams are
+                              // non-blocking (they do not wait for the null stream): wait here
+                              hipStreamSynchronize(nullptr) == hipSuccess;
+                if (ok && !copied) {
+                    // staged copy: source device -> pinned host -> this device (what the peer copy does without a link)
+                    (void)hipGetLastError();
+                    void* hp = nullptr;
+                    copied = hipHostMalloc(&hp, floats * 4, hipHostMallocDefault) == hipSuccess;
+                    for (int rail = 0; copied && rail < 2; ++rail) {
+                        copied = hipSetDevice(src_device) == hipSuccess &&
+                                 hipMemcpy(hp, rail ? pq : pi, floats * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                                 hipSetDevice(dev) == hipSuccess &&
+                                 hipMemcpy(rail ? tq : ti, hp, floats * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    }
+                    (void)hipSetDevice(dev);
+                    if (hp) (void)hipHostFree(hp);
+                    if (copied)
+                        fprintf(stderr, "libwspr_mi355x: segments %d..%d reached device %d through the host (peer %s)\n", lo, hi,
+                                dev, peer_ok ? "copy failed" : "access refused");
+                }
+                if (!copied) {
+                    fprintf(stderr, "libwspr_mi355x: copy of segments %d..%d to device %d failed\n", lo, hi, dev);
                     if (ti) (void)hipFree(ti);
                     if (tq) (void)hipFree(tq);
                     rcs[k] = -1;

@@ -63,7 +63,7 @@ def test_product_reads_five_environment_variables_and_no_kernel_switch():
     knobs = [b"WSPR_HOST_THREADS", b"WSPR_SLOTS", b"WSPR_BLOCKING_SYNC", b"WSPR_FANO_DEVICE", b"WSPR_FANO_FAST"]
     switches = [b"WSPR_K0_KERNEL", b"WSPR_K0_RESIDENT", b"WSPR_K0_CUS", b"WSPR_K1_FUSED", b"WSPR_K3_KERNEL", b"WSPR_K4_LAG",
                 b"WSPR_K4_FREQ", b"WSPR_K4_DRIFT", b"WSPR_REPEAT_LAG", b"WSPR_REPEAT_FREQ", b"WSPR_REPEAT_FANO",
-                b"WSPR_FANO_WAVE_CAP", b"WSPR_NODE_VIRTUAL"]
+                b"WSPR_FANO_WAVE_CAP", b"WSPR_NODE_VIRTUAL", b"WSPR_NODE_FAIL_PEER", b"WSPR_NODE_FAIL_SHARD"]
     assert all(k in prod for k in knobs)
     assert not [k for k in switches if k in prod]
     assert all(k in lab for k in switches)

@@ -423,7 +423,9 @@ def test_world8_hashtable_without_turns_through_the_product(tmp_path):
     assert got == ref and open(shared / "hashtable.txt").read() == ref_file
     resolved = sum(m.startswith("<") and not m.startswith("<...>") for seg in got for m in seg)
     print("world 8 -H: rounds per rank %r, %d resolved type-3 spots of %d spots" % (rounds, resolved, sum(len(g) for g in got)))
-    assert resolved >= 6 and len(rounds) == 8 and all(1 <= r <= 9 for r in rounds) and max(rounds) >= 2
+    # (a rank revisits once it has seen its predecessors' stores, but a type-3 decode stores nothing: the store lists do not
+    # change and the exchange is over after the first round)
+    assert resolved >= 6 and len(rounds) == 8 and all(1 <= r <= 9 for r in rounds)
 
 
 # ---- real-input fan-out: rank 0 holds the IQ, the other ranks receive their rows -----------------

@@ -1,0 +1,87 @@
+"""The one stage whose arithmetic is not the reference's is the 512-point FFT (reference: FFTW single precision,
+wsprd/wsprd.c:496-500, :544; product and oracle: one float32 radix-2 DIF).  How much that can matter is MEASURED, not
+assumed: oracle/orc_fft_alt.c holds seven other FFTs (a float64 one rounded to float32, five other float32
+factorisations, one with fused multiply-add twiddles), tools/fft_robustness.py decodes BASELINE configs[1], configs[2]
+and 3 000 random scenes through the oracle with each of them and counts what changes in the spot lists
+(profiles/r06_fft_robustness.json).  Here, on CPU:
+  * every variant IS a 512-point DFT (against numpy's float64 FFT), so the study perturbs roundings and nothing else;
+  * on a fixed sample of the study's own segments the counts stay under the ceilings the full study supports:
+    no segment gains or loses a spot, no call/loc/pwr changes, |dSNR| <= 1e-3 dB (north_star allows 0.1 dB),
+    dt and freq unchanged (north_star: 10 ms, 0.1 Hz);
+  * the committed full-size result says the same for all 8 192 + 1 024 + 3 000 segments."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture()
+def variant_guard():
+    yield
+    ol.lib().orc_set_fft_variant(0)
+
+
+def test_every_variant_is_a_dft(variant_guard):
+    L = ol.lib()
+    rng = np.random.default_rng(512)
+    x = rng.normal(size=512) + 1j * rng.normal(size=512)
+    x32 = x.real.astype(np.float32) + 1j * x.imag.astype(np.float32)
+    ref = np.fft.fft(x32.astype(np.complex128))
+    errs = {}
+    for v in range(8):
+        assert L.orc_set_fft_variant(v) == 0
+        re = x32.real.astype(np.float32).copy(); im = x32.imag.astype(np.float32).copy()
+        (L.orc_fft512 if v == 0 else L.orc_fft512_variant)(ol.ptr(re), ol.ptr(im))
+        errs[v] = float(np.abs(re.astype(np.float64) + 1j * im - ref).max() / np.abs(ref).max())
+    assert L.orc_set_fft_variant(8) == -1 and L.orc_set_fft_variant(-1) == -1
+    assert all(e < 4e-7 for e in errs.values()), errs
+    assert errs[1] < 6e-8                                   # the float64 one is the correctly rounded answer
+    # and the variants really differ from variant 0 in the last bits (or the study would compare a thing with itself)
+    L.orc_set_fft_variant(0)
+    re0 = x32.real.astype(np.float32).copy(); im0 = x32.imag.astype(np.float32).copy()
+    L.orc_fft512(ol.ptr(re0), ol.ptr(im0))
+    for v in range(1, 8):
+        L.orc_set_fft_variant(v)
+        re = x32.real.astype(np.float32).copy(); im = x32.imag.astype(np.float32).copy()
+        L.orc_fft512_variant(ol.ptr(re), ol.ptr(im))
+        assert not (np.array_equal(re, re0) and np.array_equal(im, im0)), v
+
+
+def test_spots_do_not_depend_on_the_fft_on_a_sample(variant_guard):
+    import fft_robustness as fr
+    L = ol.lib()
+    segs = [fr.gen_c2_one(s) for s in range(12)] + fr.gen_scenes(24, seed=777) + fr.gen_c1(8)
+    L.orc_set_fft_variant(0)
+    base = fr.decode_all(segs, 4, True)
+    assert sum(len(b) for b, _ in base) > 120
+    for v in (1, 4, 6):
+        L.orc_set_fft_variant(v)
+        r = fr.compare(base, fr.decode_all(segs, 4, True))
+        assert r["segments_spot_set_differs"] == 0 and r["spots_lost"] == 0 and r["spots_gained"] == 0, (v, r)
+        assert r["spots_text_changed"] == 0 and r["spots_order_changed_segments"] == 0, (v, r)
+        assert r["max_dsnr_db"] <= 1e-3 and r["max_ddt_s"] == 0.0 and r["max_dfreq_hz"] == 0.0, (v, r)
+        assert r["spots_drift_changed"] == 0 and r["spots_jitter_changed"] == 0 and r["spots_cycles_changed"] == 0, (v, r)
+        assert r["spots_bit_identical"] < r["spots_base"]       # the SNR's last bits DO move: ps really was perturbed
+
+
+def test_committed_full_size_study_stays_under_its_ceilings():
+    """profiles/r06_fft_robustness.json (tools/fft_robustness.py, run in the build container): for every workload and
+    every alternative FFT, the share of segments whose spot set differs <= 0.1 %, no spot beyond the north-star
+    tolerances, no call/loc/pwr change among matched spots."""
+    path = os.path.join(ROOT, "profiles", "r06_fft_robustness.json")
+    d = json.load(open(path))
+    assert set(d["workloads"]) >= {"c1", "c2", "scenes"}
+    assert d["workloads"]["c2"]["segments"] == 8192 and d["workloads"]["scenes"]["segments"] == 3000
+    for wl, blk in d["workloads"].items():
+        assert len(blk["by_variant"]) >= 7, wl
+        for v, r in blk["by_variant"].items():
+            assert r["segments_spot_set_differs"] <= 1e-3 * r["segments"], (wl, v, r)
+            assert r["spots_beyond_tolerance"] == 0 and r["spots_text_changed"] == 0, (wl, v, r)
+            assert r["max_dsnr_db"] <= 0.1 and r["max_ddt_s"] <= 0.010 and r["max_dfreq_hz"] <= 0.1, (wl, v, r)

@@ -909,3 +909,29 @@ def test_node_level_call_equals_one_device_batch(w, synth_batch, monkeypatch):
     out = (w.decoder_results * (nseg * 16))(); nres = (C.c_int * nseg)()
     assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), ndev + 3, nseg, NS, NS, w.default_options(),
                                            C.addressof(out), 16, C.addressof(nres), 0) == -1
+    # more devices than are visible (without the test hook's virtual devices): the documented -1, no spots
+    monkeypatch.delenv("WSPR_NODE_VIRTUAL")
+    nres = (C.c_int * nseg)(*([7] * nseg))
+    assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), 0, nseg, NS, NS, w.default_options(),
+                                           C.addressof(out), 16, C.addressof(nres), ndev + 1) == -1 and not any(nres)
+    monkeypatch.setenv("WSPR_NODE_VIRTUAL", "1")
+    # every peer copy reports failure (fault injection of the lab build): the blocks travel through pinned host memory
+    # instead and the spots are the same
+    monkeypatch.setenv("WSPR_NODE_FAIL_PEER", "1")
+    out = (w.decoder_results * (nseg * 16))(); nres = (C.c_int * nseg)()
+    assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), 0, nseg, NS, NS, w.default_options(),
+                                           C.addressof(out), 16, C.addressof(nres), 3 * ndev) == 0
+    assert [[_spot_tuple(out[s * 16 + i]) for i in range(nres[s])] for s in range(nseg)] == want
+    monkeypatch.delenv("WSPR_NODE_FAIL_PEER")
+    # one shard fails: the WHOLE call fails and reports no spots (include/wspr_mi355x.h), the inputs are untouched and the
+    # call can be repeated
+    monkeypatch.setenv("WSPR_NODE_FAIL_SHARD", "1")
+    nres = (C.c_int * nseg)(*([7] * nseg))
+    assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), 0, nseg, NS, NS, w.default_options(),
+                                           C.addressof(out), 16, C.addressof(nres), 3 * ndev) < 0 and not any(nres)
+    monkeypatch.delenv("WSPR_NODE_FAIL_SHARD")
+    assert torch.equal(dI.cpu(), torch.from_numpy(I)) and torch.equal(dQ.cpu(), torch.from_numpy(Q))
+    out = (w.decoder_results * (nseg * 16))(); nres = (C.c_int * nseg)()
+    assert L.wspr_decode_batch_node_device(dI.data_ptr(), dQ.data_ptr(), 0, nseg, NS, NS, w.default_options(),
+                                           C.addressof(out), 16, C.addressof(nres), 3 * ndev) == 0
+    assert [[_spot_tuple(out[s * 16 + i]) for i in range(nres[s])] for s in range(nseg)] == want

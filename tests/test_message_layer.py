@@ -116,3 +116,51 @@ def test_encode_fano_roundtrip_like_reference_unit_test(L):
     assert L.pack_call(b"TOOLONG1") == 0
     partab = (C.c_ubyte * 256).in_dll(L, "Partab")
     assert [partab[i] for i in (0, 1, 3, 7, 255, 128)] == [0, 1, 0, 1, 0, 1]
+
+
+def test_unpack_and_channel_symbols_against_the_real_reference_objects(L):
+    """The decoder's per-decode host work (unpk_ on the decoded bits, get_wspr_channel_symbols on the text for the
+    subtraction) is written for speed since round 6 (texts put together by hand, the encoder + interleaver as XORs of
+    fixed patterns): against oracle/_ref (the reference's own wsprd_utils.c / wsprsim_utils.c / fano.c / nhash.c) on
+    20 000 random 50-bit messages of every type, and on the texts they unpack to, with the hash tables carried along."""
+    R = ol.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref/libwsprd_ref.so not present")
+    import synth
+    rng = np.random.default_rng(2026)
+
+    def tables():
+        return C.create_string_buffer(32768 * 13), C.create_string_buffer(32768 * 5)
+    ph, pl = tables(); rh, rl = tables()
+
+    def unpk(lib, fn, d, hashtab, loctab):
+        msg = (C.c_byte * 12)(*[(b - 256 if b > 127 else b) for b in d] + [0] * 5)
+        clp = C.create_string_buffer(23); call = C.create_string_buffer(13); loc = C.create_string_buffer(7)
+        pwr = C.create_string_buffer(3); cs = C.create_string_buffer(13)
+        r = getattr(lib, fn)(msg, hashtab, loctab, clp, call, loc, pwr, cs)
+        return int(r), clp.value, call.value, loc.value, pwr.value, cs.value
+
+    def symbols(lib, text, hashtab, loctab):
+        sym = (C.c_ubyte * 162)(); msg = C.create_string_buffer(text, 32)
+        ok = lib.get_wspr_channel_symbols(msg, hashtab, loctab, sym)
+        return int(ok), bytes(sym) if ok else None
+    L.get_wspr_channel_symbols.restype = C.c_int
+    n_types = [0, 0, 0]
+    for t in range(20000):
+        if t % 4 == 0:                                   # a valid plain message (the common case) ...
+            msg = synth.message_wide(int(rng.integers(0, 1 << 62))).encode()
+            ok, s = symbols(R, msg, rh, rl)
+            assert (ok, s) == symbols(L, msg, ph, pl), msg
+            continue
+        n = int(rng.integers(0, 1 << 28)); m = int(rng.integers(0, 1 << 22))        # ... and arbitrary bits
+        d = [(n >> 20) & 255, (n >> 12) & 255, (n >> 4) & 255, ((n & 15) << 4) | ((m >> 18) & 15),
+             (m >> 10) & 255, (m >> 2) & 255, (m & 3) << 6]
+        want = unpk(R, "unpk_", d, rh, rl)
+        assert unpk(L, "unpk_", d, ph, pl) == want, d
+        ntype = (m & 127) - 64
+        n_types[0 if ntype < 0 else (1 if ntype % 10 in (0, 3, 7) else 2)] += 1
+        if want[0] == 0 and b"." not in want[1] and want[1].isascii():          # the decoder re-encodes what it prints
+            ok, s = symbols(R, want[1], rh, rl)
+            assert (ok, s) == symbols(L, want[1], ph, pl), want[1]
+    assert min(n_types) > 1000
+    assert ph.raw == rh.raw and pl.raw == rl.raw          # the hash memories saw the same stores
