@@ -1037,11 +1037,15 @@ int Context::bench_valu(int nseg, int samples, int iters, double* ms) {
         char msg[32] = "K1JT FN20 20";
         if (!channel_symbols(msg, hashtab.data(), loctab.data(), sym)) return -1;
     }
+    // WSPR_BENCH_VALU_REUSE=k (a measurement switch): the candidates take their samples from k segments only, so that the
+    // kernels find them in the caches -- what a launch set costs when its sample reads are free (the results are not used)
+    const char* reuse_env = lab_env("WSPR_BENCH_VALU_REUSE");
+    const int reuse = reuse_env ? std::max(1, atoi(reuse_env)) : nseg;
     for (int s = 0; s < nseg; ++s) {
         if (npk[s] <= 0) continue;
         const DevCand& cd = cand[(size_t)s * kMaxCand];
         FineState f{};
-        f.seg = s; f.freq = cd.freq; f.drift = 0.0f; f.shift = cd.shift; f.sync = cd.sync;
+        f.seg = s % reuse; f.freq = cd.freq; f.drift = 0.0f; f.shift = cd.shift; f.sync = cd.sync;
         f.shift_coarse = cd.shift; f.freq_coarse = cd.freq;
         items.push_back(f);
         SubJob jb{};

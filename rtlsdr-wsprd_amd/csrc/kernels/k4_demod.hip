@@ -905,6 +905,11 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
 // in registers, costs eight vector instructions -- 32 cycles -- per step.)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// kAblate (measurements only, WSPR_FQ_ABLATE in the lab build; 0 = the kernel): 1 = the samples are staged once, the later
+// chunks reuse the tile (no sample loads, no tile writes, no barriers); 2 = the table words are fetched once (no table
+// loads in the loop); 4 = no MFMA (the lane's own words as operands); 8 = no tile reads (one sample pair for all steps).
+// The sums are then wrong, the instruction mix that remains is what is timed.
+template <int kAblate>
 __global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
 void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
                        const FineState* __restrict__ items, const int* __restrict__ item_list,
@@ -952,10 +957,16 @@ void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ d
     acc.clear();
     // the two steps of one pair: the lane's (c, s) of its tone for both steps spread over the wave, then the sums
     auto pair_steps = [&](const float4 tv, const float2 x0, const float2 x1) {
-        const v4f c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.x, 1.0f, zero, 0, 0, 0);
-        const v4f s0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.y, 1.0f, zero, 0, 0, 0);
-        const v4f c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.z, 1.0f, zero, 0, 0, 0);
-        const v4f s1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.w, 1.0f, zero, 0, 0, 0);
+        v4f c0, s0, c1, s1;
+        if (kAblate & 4) {
+            c0 = (v4f){tv.x, tv.y, tv.z, tv.w}; s0 = (v4f){tv.y, tv.z, tv.w, tv.x};
+            c1 = (v4f){tv.z, tv.w, tv.x, tv.y}; s1 = (v4f){tv.w, tv.x, tv.y, tv.z};
+        } else {
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.x, 1.0f, zero, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.y, 1.0f, zero, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.z, 1.0f, zero, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.w, 1.0f, zero, 0, 0, 0);
+        }
         acc.step(x0, make_float4(c0[0], c0[1], c0[2], c0[3]), make_float4(s0[0], s0[1], s0[2], s0[3]));
         // (instruction selection otherwise sinks the serial adds of a whole unrolled trip below all of its products -- 32
         // registers per step pair -- and spills: the accumulators are pinned after every step)
@@ -964,6 +975,7 @@ void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ d
         asm volatile("" : "+v"(acc.i01), "+v"(acc.i23), "+v"(acc.q01), "+v"(acc.q23));
     };
     for (int c = 0; c < kSps / kFsChunk; ++c) {
+        if (!(kAblate & 1) || c == 0) {
         __syncthreads();                                             // the previous chunk has been consumed
 #pragma unroll
         for (int u = 0; u < kFqPerThread; ++u) {
@@ -971,6 +983,7 @@ void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ d
             if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = ((okmask >> u) & 1u) ? nxt[u] : make_float2(0.0f, 0.0f);
         }
         __syncthreads();
+        }
         // the chunk's sixteen step pairs, unrolled: pair gg works on the table words fetched kAhead pairs ago and on the
         // samples read from the tile one pair ago, and issues both fetches for its successors.  The next chunk's samples
         // are requested after pair 0: vector loads complete in order, so a table word requested after them cannot be waited
@@ -979,12 +992,12 @@ void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ d
         float2 x0 = tile[srow][0], x1 = tile[srow][1];
 #pragma unroll
         for (int gg = 0; gg < kFsChunk / 2; ++gg) {
-            if (gg == 1) fetch(c + 1);                               // (after the last chunk: fetched, masked or not, and never stored)
+            if (gg == 1 && !(kAblate & 1)) fetch(c + 1);             // (after the last chunk: fetched, masked or not, and never stored)
             const float4 tv = tq[gg % kAhead];
             const float2 y0 = x0, y1 = x1;
-            if (gg + 1 < kFsChunk / 2) { x0 = tile[srow][2 * gg + 2]; x1 = tile[srow][2 * gg + 3]; }
+            if (gg + 1 < kFsChunk / 2 && !(kAblate & 8)) { x0 = tile[srow][2 * gg + 2]; x1 = tile[srow][2 * gg + 3]; }
             const int gn = gbase + gg + kAhead;
-            tq[gg % kAhead] = gt[4 * (gn < kPairs ? gn : kPairs - 1)];
+            if (!(kAblate & 2)) tq[gg % kAhead] = gt[4 * (gn < kPairs ? gn : kPairs - 1)];
             pair_steps(tv, y0, y1);
         }
     }
@@ -1253,9 +1266,21 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     if (n_shared > 0) {
         if (bcast) {
             hipLaunchKernelGGL(phasor_freq_kernel<true>, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-            for (int r = 0; r < rep_freq; ++r)
-                hipLaunchKernelGGL(freq_bcast_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
-                                   list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
+            static const int ablate = [] { const char* e = lab_env("WSPR_FQ_ABLATE"); return e ? atoi(e) : 0; }();
+            for (int r = 0; r < rep_freq; ++r) {
+#define WSPR_FQ_LAUNCH(A) hipLaunchKernelGGL(freq_bcast_kernel<A>, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items, \
+                                             list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep)
+                switch (ablate) {
+                    case 1: WSPR_FQ_LAUNCH(1); break;
+                    case 2: WSPR_FQ_LAUNCH(2); break;
+                    case 3: WSPR_FQ_LAUNCH(3); break;
+                    case 7: WSPR_FQ_LAUNCH(7); break;
+                    case 11: WSPR_FQ_LAUNCH(11); break;
+                    case 15: WSPR_FQ_LAUNCH(15); break;
+                    default: WSPR_FQ_LAUNCH(0); break;
+                }
+#undef WSPR_FQ_LAUNCH
+            }
         } else {
         hipLaunchKernelGGL(phasor_freq_kernel<false>, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
         for (int r = 0; r < rep_freq; ++r)
