@@ -789,10 +789,6 @@ __device__ __forceinline__ int centre_from_lag_scan(const FineState& st, int nla
     return m < nlag ? m : -1;
 }
 
-// kToneMajor (the layout freq_bcast_kernel reads): the four scanned hypotheses' tables are stored per PAIR of steps as
-// [tone][step parity][c, s] -- sixteen floats of which lane l of a wave fetches the four of tone l mod 4 as one 16-byte
-// load; the centre hypothesis (only freq_centre_rare_kernel reads it) keeps the step-major layout [step][c0..c3, s0..s3].
-template <bool kToneMajor>
 __global__ __launch_bounds__(64)
 void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restrict__ item_list, int ifmin,
                         float fstep, float* __restrict__ tabs) {
@@ -800,7 +796,6 @@ void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restri
     if (lane >= 4 * kNFreq) return;
     const FineState st = items[item_list[slot]];
     const int f = lane >> 2, tone = lane & 3;
-    const bool tone_major = kToneMajor && f != kNFreq / 2;
     const float f0 = st.freq + (float)(ifmin + f) * fstep;
     const float fp = (float)((double)f0 + ((double)st.drift / 2.0) * (double)(0.0f - 81.0f) / (double)81.0f);
     const double off = (tone == 0) ? -kDf15 : (tone == 1) ? -kDf05 : (tone == 2) ? kDf05 : kDf15;
@@ -814,13 +809,8 @@ void phasor_freq_kernel(const FineState* __restrict__ items, const int* __restri
             c = a - b;
             s = e + d;
         }
-        if (tone_major) {
-            t[16 * (j >> 1) + 4 * tone + 2 * (j & 1)] = c;
-            t[16 * (j >> 1) + 4 * tone + 2 * (j & 1) + 1] = s;
-        } else {
-            t[8 * j + tone] = c;
-            t[8 * j + 4 + tone] = s;
-        }
+        t[8 * j + tone] = c;
+        t[8 * j + 4 + tone] = s;
     }
 }
 
@@ -891,120 +881,13 @@ void freq_scalar_kernel(const float* __restrict__ dI, const float* __restrict__ 
         pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
 }
 
-// Round 6: the table in REGISTERS, handed to the lanes by the matrix pipe.  What the waves of freq_scalar_kernel wait for
-// is the table (32 KB per candidate, used once, streamed through a 16 KB scalar cache one stage ahead: round 5).  Here a
-// lane fetches, with ordinary vector loads several steps ahead, the (cos, sin) of ONE tone (tone = lane mod 4) for a pair
-// of steps, and V_MFMA_F32_4X4X1_16B_F32 spreads them: with A = the lane's value, B = 1.0 and C = 0 the instruction leaves
-// D[i] = A(lane 4b + i) x 1.0 + 0 in register i of EVERY lane of block b -- and every block holds the same four values,
-// so register i is tone i's phasor in all 64 lanes.  T x 1 + 0 is exact whatever the pipe's internal rounding (fused, round
-// to nearest, denormals kept: tools/mfma_f32_rounding_probe.hip), so the operands of the packed multiplies are the
-// table's bits and the sums are those of freq_scalar_kernel, operation for operation (trace parity).  Cost per step: two
-// 2-pass MFMAs (16 cycles of the SIMD, the fp32 matrix and vector pipes do not overlap on this part: round 4) beside the
-// sixteen packed instructions (64 cycles), nothing through the scalar cache, no SGPR operands.  Same workgroup shape,
-// sample staging and outputs as freq_scalar_kernel.  (v_readlane_b32 into SGPR pairs, the other way to keep the table
-// in registers, costs eight vector instructions -- 32 cycles -- per step.)
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// kAblate (measurements only, WSPR_FQ_ABLATE in the lab build; 0 = the kernel): 1 = the samples are staged once, the later
-// chunks reuse the tile (no sample loads, no tile writes, no barriers); 2 = the table words are fetched once (no table
-// loads in the loop); 4 = no MFMA (the lane's own words as operands); 8 = no tile reads (one sample pair for all steps).
-// The sums are then wrong, the instruction mix that remains is what is timed.
-template <int kAblate>
-__global__ __launch_bounds__(kFqThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
-void freq_bcast_kernel(const float* __restrict__ dI, const float* __restrict__ dQ, int np,
-                       const FineState* __restrict__ items, const int* __restrict__ item_list,
-                       const float* __restrict__ tabs, float4* __restrict__ pw_out,
-                       const float4* __restrict__ pw_lag, int nlag, int lagstep) {
-    __shared__ float2 tile[kNSymD][kFsChunk + 1];
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    const int item = item_list[slot];
-    const FineState st = items[item];
-    const float* __restrict__ xi = dI + (size_t)st.seg * kIqStride;
-    const float* __restrict__ xq = dQ + (size_t)st.seg * kIqStride;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = wave / 3, sym = (wave - 3 * h) * 64 + (tid & 63);
-    const int f = h < kNFreq / 2 ? h : h + 1;
-    const int m_centre = centre_from_lag_scan(st, nlag, lagstep);          // block-uniform
-    const bool working = sym < kNSymD;
-    const int srow = working ? sym : kNSymD - 1;                           // idle lanes run along (the MFMA wants them) on the last row
-    // tone-major table of hypothesis f: 128 step pairs x [tone][parity][c, s]; this lane's tone = lane mod 4
-    const float4* __restrict__ gt = reinterpret_cast<const float4*>(tabs) + ((size_t)slot * kNFreq + f) * (2 * kSps) + (tid & 3);
-    constexpr int kAhead = 4;                                              // step pairs whose table words are in flight per lane
-    constexpr int kPairs = kSps / 2;
-
-    // staging loads without branches (a masked element reads sample 0 and is zeroed when it is stored): the loads of a
-    // chunk are then one straight run of vector loads, and the waits for the table words around them count exactly
-    float2 nxt[kFqPerThread];
-    unsigned okmask = 0;
-    auto fetch = [&](int c) {
-        okmask = 0;
-#pragma unroll
-        for (int u = 0; u < kFqPerThread; ++u) {
-            const int e = u * kFqThreads + tid, row = e >> 5, col = e & (kFsChunk - 1);
-            const int k = st.shift + kSps * row + kFsChunk * c + col;
-            const bool ok = (e < kNSymD * kFsChunk) && (k > 0) && (k < np);
-            const int kc = ok ? k : 0;
-            nxt[u] = make_float2(xi[kc], xq[kc]);
-            okmask |= ok ? (1u << u) : 0u;
-        }
-    };
-    fetch(0);
-    float4 tq[kAhead];
-#pragma unroll
-    for (int a = 0; a < kAhead; ++a) tq[a] = gt[4 * a];
-    const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    ToneAcc acc;
-    acc.clear();
-    // the two steps of one pair: the lane's (c, s) of its tone for both steps spread over the wave, then the sums
-    auto pair_steps = [&](const float4 tv, const float2 x0, const float2 x1) {
-        v4f c0, s0, c1, s1;
-        if (kAblate & 4) {
-            c0 = (v4f){tv.x, tv.y, tv.z, tv.w}; s0 = (v4f){tv.y, tv.z, tv.w, tv.x};
-            c1 = (v4f){tv.z, tv.w, tv.x, tv.y}; s1 = (v4f){tv.w, tv.x, tv.y, tv.z};
-        } else {
-            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.x, 1.0f, zero, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.y, 1.0f, zero, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.z, 1.0f, zero, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_4x4x1f32(tv.w, 1.0f, zero, 0, 0, 0);
-        }
-        acc.step(x0, make_float4(c0[0], c0[1], c0[2], c0[3]), make_float4(s0[0], s0[1], s0[2], s0[3]));
-        // (instruction selection otherwise sinks the serial adds of a whole unrolled trip below all of its products -- 32
-        // registers per step pair -- and spills: the accumulators are pinned after every step)
-        asm volatile("" : "+v"(acc.i01), "+v"(acc.i23), "+v"(acc.q01), "+v"(acc.q23));
-        acc.step(x1, make_float4(c1[0], c1[1], c1[2], c1[3]), make_float4(s1[0], s1[1], s1[2], s1[3]));
-        asm volatile("" : "+v"(acc.i01), "+v"(acc.i23), "+v"(acc.q01), "+v"(acc.q23));
-    };
-    for (int c = 0; c < kSps / kFsChunk; ++c) {
-        if (!(kAblate & 1) || c == 0) {
-        __syncthreads();                                             // the previous chunk has been consumed
-#pragma unroll
-        for (int u = 0; u < kFqPerThread; ++u) {
-            const int e = u * kFqThreads + tid;
-            if (e < kNSymD * kFsChunk) tile[e >> 5][e & (kFsChunk - 1)] = ((okmask >> u) & 1u) ? nxt[u] : make_float2(0.0f, 0.0f);
-        }
-        __syncthreads();
-        }
-        // the chunk's sixteen step pairs, unrolled: pair gg works on the table words fetched kAhead pairs ago and on the
-        // samples read from the tile one pair ago, and issues both fetches for its successors.  The next chunk's samples
-        // are requested after pair 0: vector loads complete in order, so a table word requested after them cannot be waited
-        // for without them -- the first such word is pair 5's, four pairs later
-        const int gbase = (kFsChunk / 2) * c;
-        float2 x0 = tile[srow][0], x1 = tile[srow][1];
-#pragma unroll
-        for (int gg = 0; gg < kFsChunk / 2; ++gg) {
-            if (gg == 1 && !(kAblate & 1)) fetch(c + 1);             // (after the last chunk: fetched, masked or not, and never stored)
-            const float4 tv = tq[gg % kAhead];
-            const float2 y0 = x0, y1 = x1;
-            if (gg + 1 < kFsChunk / 2 && !(kAblate & 8)) { x0 = tile[srow][2 * gg + 2]; x1 = tile[srow][2 * gg + 3]; }
-            const int gn = gbase + gg + kAhead;
-            if (!(kAblate & 2)) tq[gg % kAhead] = gt[4 * (gn < kPairs ? gn : kPairs - 1)];
-            pair_steps(tv, y0, y1);
-        }
-    }
-    if (working) pw_out[((size_t)slot * kNFreq + f) * kNSymD + sym] = acc.amplitudes();
-    if (m_centre >= 0 && h == 0 && working)
-        pw_out[((size_t)slot * kNFreq + kNFreq / 2) * kNSymD + sym] = pw_lag[((size_t)item * nlag + m_centre) * kNSymD + sym];
-}
+// Round 6 kept the table in REGISTERS instead: a lane fetched the (cos, sin) of one tone for a pair of steps with vector
+// loads four pairs ahead and V_MFMA_F32_4X4X1_16B_F32 (B = 1.0, C = 0: D[i] = A(lane 4b + i) x 1 + 0, exact) spread them
+// over the wave -- operands in VGPRs, nothing through the scalar cache.  Bit-identical (trace parity) and NOT faster:
+// 375 us against 367 us per 2 048 candidates for this kernel, because the table is ~45 us of it; the bare arithmetic (sixteen
+// packed instructions and one tile read per step) takes 242 us, 0.70 of its issue bound like the lag scan and the
+// subtraction, staging and barriers ~60 us (profiles/r06_freq_scan_table_in_registers_ab.txt).  The kernel was deleted again;
+// the experiment is in the history (commit "freq_bcast_kernel: ablation switches ...").
 
 // Round 5 tried these sums with NO LDS and NO barrier (verdict of round 4: VALU active 11 % of the wave cycles, 69 %
 // waiting): a wave on its own, lane = symbol, the lane's 8 or 16 samples of a chunk in registers with the next chunk's
@@ -1261,32 +1144,11 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     // WSPR_K4_FREQ=nocentre: no centre hypothesis is taken from the lag scan (every candidate through the rare path)
     static const bool nocentre = [] { const char* e = lab_env("WSPR_K4_FREQ"); return e && e[0] == 'n'; }();
     const int nlag_c = (pl && !nocentre) ? nlag_lag : 0;
-    // WSPR_K4_FREQ=bcast: the table handed to the lanes by the matrix pipe (freq_bcast_kernel) instead of the scalar cache
-    static const bool bcast = [] { const char* e = lab_env("WSPR_K4_FREQ"); return e && e[0] == 'b'; }();
     if (n_shared > 0) {
-        if (bcast) {
-            hipLaunchKernelGGL(phasor_freq_kernel<true>, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
-            static const int ablate = [] { const char* e = lab_env("WSPR_FQ_ABLATE"); return e ? atoi(e) : 0; }();
-            for (int r = 0; r < rep_freq; ++r) {
-#define WSPR_FQ_LAUNCH(A) hipLaunchKernelGGL(freq_bcast_kernel<A>, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items, \
-                                             list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep)
-                switch (ablate) {
-                    case 1: WSPR_FQ_LAUNCH(1); break;
-                    case 2: WSPR_FQ_LAUNCH(2); break;
-                    case 3: WSPR_FQ_LAUNCH(3); break;
-                    case 7: WSPR_FQ_LAUNCH(7); break;
-                    case 11: WSPR_FQ_LAUNCH(11); break;
-                    case 15: WSPR_FQ_LAUNCH(15); break;
-                    default: WSPR_FQ_LAUNCH(0); break;
-                }
-#undef WSPR_FQ_LAUNCH
-            }
-        } else {
-        hipLaunchKernelGGL(phasor_freq_kernel<false>, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
+        hipLaunchKernelGGL(phasor_freq_kernel, dim3(n_shared), dim3(64), 0, st, items, list_shared, -2, 0.1f, tabs);
         for (int r = 0; r < rep_freq; ++r)
             hipLaunchKernelGGL(freq_scalar_kernel, dim3(n_shared), dim3(kFqThreads), 0, st, dI, dQ, samples, items,
                                list_shared, tabs, reinterpret_cast<float4*>(pw), pl, nlag_c, lagstep);
-        }
         hipLaunchKernelGGL(freq_centre_rare_kernel, dim3(n_shared), dim3(64), 0, st, dI, dQ, samples, items, list_shared,
                            tabs, reinterpret_cast<float4*>(pw), nlag_c, lagstep);
         hipLaunchKernelGGL(freq_metric_kernel, dim3(n_shared), dim3(64), 0, st,
