@@ -117,7 +117,11 @@ int wspr_decode_batch(float *idat, float *qdat, int nseg, int samples, size_t se
  * Protocol for R shards (rtlsdr-wsprd_amd/dist.py decode_hashed_sharded): every shard calls with no prior and
  * WSPR_HASH_KEEP_FILE; the stores are exchanged; a shard whose predecessors' stores changed calls again with
  * WSPR_HASH_REVISIT (same buffers and result arrays: only the affected segments are decoded again); when no store list
- * changes any more, ONE process calls wspr_hash_commit() with all stores in segment order. */
+ * changes any more, ONE process calls wspr_hash_commit() with all stores in segment order.
+ * WSPR_HASH_REVISIT is refused (negative return, results untouched) unless the calling thread's previous hashed call
+ * completed over the same segments, samples and slot layout and the library's working buffers have not been released
+ * since.  Calls with WSPR_HASH_KEEP_FILE or a prior are ordered by a process-wide turn which they keep while they decode:
+ * shards driven from several threads of one process run one after the other; give every shard its own process (dist.py). */
 typedef struct wspr_hash_op {
     int32_t seg;                /* global segment index */
     int32_t slot;               /* 0 .. HASHTAB_SIZE - 1 */

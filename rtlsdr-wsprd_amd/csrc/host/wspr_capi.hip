@@ -224,11 +224,18 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
     HashChain::Ticket ticket(HashChain::get());
     const bool revisit = (flags & WSPR_HASH_REVISIT) != 0;
     // a plain batch call (all of its job in one call, the file its own to write) may run its first round ahead of its
-    // turn; a shard of a larger job is driven round by round from outside and waits first
+    // turn; a shard of a larger job is driven round by round from outside and waits first -- and keeps its turn for the
+    // whole call, so shards driven from several threads of ONE process (several devices or lanes) decode one after the
+    // other (include/wspr_mi355x.h says so; shards in different processes -- rtlsdr-wsprd_amd/dist.py -- do not meet here)
     const bool ahead = !revisit && !(flags & WSPR_HASH_KEEP_FILE) && n_prior <= 0;
     if (!ahead) ticket.wait_turn();
-    if (revisit && !(t_hash && (int)t_hash->log.size() == nseg && t_hash->seg0 == seg_index0))
-        throw std::runtime_error("WSPR_HASH_REVISIT without a matching previous call on this thread");
+    // a revisit works on the state the previous call of this thread left: its log, and the decoded rows in the slots'
+    // working buffers.  It is refused unless that call COMPLETED (a call that threw leaves a half-updated log) over the
+    // same segments, samples and slot layout (wspr_set_thread_slots / a node-level share in between change the shares)
+    const int nslots_now = (nseg >= 128) ? Context::slot_cap() : 1;
+    if (revisit && !(t_hash && t_hash->valid && (int)t_hash->log.size() == nseg && t_hash->seg0 == seg_index0 &&
+                     t_hash->samples == samples && t_hash->nslots == nslots_now))
+        throw std::runtime_error("WSPR_HASH_REVISIT without a matching, completed previous call on this thread");
     if (!revisit) {
         t_hash.reset(new wspr::HashBatch);
         t_hash->load_file();
@@ -236,6 +243,8 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
         t_hash->resize(nseg);
     }
     wspr::HashBatch& hb = *t_hash;
+    hb.valid = false;                                      // until this call has run to its end
+    hb.nslots = nslots_now; hb.samples = samples;
     hb.rounds = hb.redecoded = 0;
     hb.prior.assign(reinterpret_cast<const wspr::HashOp*>(prior), reinterpret_cast<const wspr::HashOp*>(prior) + std::max(0, n_prior));
     std::stable_sort(hb.prior.begin(), hb.prior.end(), [](const wspr::HashOp& a, const wspr::HashOp& b) { return a.seg < b.seg; });
@@ -244,6 +253,7 @@ int decode_hashed(int nseg, int samples, const decoder_options& options, decoder
     decode_split(nseg, samples, options, decodes, max_results, n_results, load, reload, writeback, idat, qdat, seg_stride,
                  nullptr, &hb, revisit ? &todo : nullptr,
                  ahead ? std::function<void()>([&] { ticket.wait_turn(); hb.load_file(); }) : std::function<void()>());
+    hb.valid = true;
     const std::vector<wspr::HashOp> st = hb.stores();
     if (n_stores) *n_stores = (int)st.size();
     if (n_redecoded) *n_redecoded = hb.redecoded;
@@ -349,6 +359,9 @@ int wspr_decode_batch_trace(float* idat, float* qdat, int nseg, int samples, siz
                                            options, decodes + (size_t)s * max_results, max_results, n_results + s, trace + s);
         });
     try {
+        // a single traced call with the option reads and writes hashtable.txt itself: in its turn, like wspr_decode_batch()
+        std::unique_ptr<HashChain::Ticket> turn;
+        if (options.usehashtable) { turn.reset(new HashChain::Ticket(HashChain::get())); turn->wait_turn(); }
         if (samples > wspr::kMaxSamples) {
             // the reference derives its block count from `samples` (wsprd.c:516) and would read past the 45 000 samples
             // its callers hold; this library's working rows are 45 000 samples, so a longer record is refused, not cut

@@ -432,6 +432,11 @@ void Context::reload_rows(const float* I, const float* Q, bool device, size_t st
                           const std::vector<int>& segs) {
     Impl& c = *d;
     const hipMemcpyKind kind = device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // the rows must still be there: a revisit (WSPR_HASH_REVISIT) comes back to working buffers a previous call filled, and
+    // wspr_release_buffers() or a smaller share in between would leave nothing, or too little, to write into
+    for (int s : segs)
+        if (s < 0 || !c.iqI.p || !c.iqQ.p || ((size_t)s + 1) * kIqStride * 4 > c.iqI.cap || ((size_t)s + 1) * kIqStride * 4 > c.iqQ.cap)
+            throw std::runtime_error("the working rows of the previous call are gone (buffers released or resized since)");
     for (int s : segs) {
         HIP_OK(hipMemcpyAsync(c.iqI.as<float>() + (size_t)s * kIqStride, I + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));
         HIP_OK(hipMemcpyAsync(c.iqQ.as<float>() + (size_t)s * kIqStride, Q + (size_t)s * stride, (size_t)samples * 4, kind, c.stream));

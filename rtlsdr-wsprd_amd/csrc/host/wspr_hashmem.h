@@ -41,6 +41,9 @@ struct HashBatch {
     std::vector<std::vector<Ver>> ver;              // per slot: last store of each storing segment, ascending seg
     std::vector<int> touched;                       // slots with versions
     int rounds = 0, redecoded = 0;
+    // what a later WSPR_HASH_REVISIT must find unchanged: the call completed (valid), over this many slots and samples
+    bool valid = false;
+    int nslots = 0, samples = 0;
 
     HashBatch();
     void load_file();                               // hashtable.txt of the working directory (wsprd.c:481-494)

@@ -268,3 +268,44 @@ def test_store_buffer_too_small_commits_nothing_and_is_completed_by_a_revisit(w,
         return first, [[_tup(out[s * K + i]) for i in range(nres[s])] for s in range(nseg)]
     (first, second), f = _in_dir(tmp_path / "retry", job)
     assert first == whole and second == whole and f == wf
+
+
+def test_revisit_is_refused_when_its_state_is_gone(w, tmp_path):
+    """WSPR_HASH_REVISIT works on what the calling thread's previous hashed call left (its log, the decoded rows in the
+    library's working buffers).  Without such a call, after wspr_release_buffers(), or with another slot layout, it must
+    fail with a negative code -- not write through a null or too small buffer (advisor, round 5) -- and a fresh call on
+    the same thread works again."""
+    nseg, K = 24, 16
+    I, Q, _ = _traffic(nseg, 0.3, 4711)
+    L = w.lib()
+    L.wspr_decode_batch_hashed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, w.decoder_options, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+    L.wspr_release_buffers.restype = C.c_size_t
+    ex = ThreadPoolExecutor(1)
+    ex.submit(L.wspr_bind_thread_lane, 5).result()
+
+    def call(flags, prior=None):
+        out = (w.decoder_results * (nseg * K))(); nres = (C.c_int * nseg)()
+        st = np.zeros((64 * nseg, 32), np.uint8); n_st = C.c_int(0)
+        pr = np.ascontiguousarray(prior if prior is not None else np.zeros((0, 32), np.uint8))
+        rc = L.wspr_decode_batch_hashed(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, _opt(w, 1), C.addressof(out), K, C.addressof(nres), 0,
+                                        100, ol.ptr(pr) if len(pr) else None, len(pr), flags, ol.ptr(st), len(st), C.byref(n_st), None)
+        return rc, [[_tup(out[s * K + i]) for i in range(nres[s])] for s in range(nseg)]
+
+    def job():
+        assert ex.submit(call, 1 | 2).result()[0] < 0                 # no previous call on this thread
+        rc, first = ex.submit(call, 1).result()
+        assert rc == 0
+        rc, again = ex.submit(call, 1 | 2).result()                   # a legitimate revisit: nothing changed, same spots
+        assert rc == 0 and again == first
+        assert L.wspr_release_buffers() > 0                           # the rows are gone ...
+        fake = np.zeros((1, 32), np.uint8); fake[0, :12] = np.frombuffer(np.array([0, 77, 2], np.int32).tobytes(), np.uint8)
+        fake[0, 12:16] = np.frombuffer(b"ZZ9Z", np.uint8)
+        rc, _ = ex.submit(call, 1 | 2, fake).result()                 # ... a revisit that has nothing to decode again may pass,
+        rc2, _ = ex.submit(call, 1 | 2).result()                      # but none may crash; a fresh call works
+        assert rc <= 0 and rc2 <= 0
+        rc, fresh = ex.submit(call, 1).result()
+        assert rc == 0 and fresh == first
+        return True
+    assert _in_dir(tmp_path / "revisit", job)[0]
