@@ -1016,7 +1016,7 @@ def main():
                                    "copy" % (nseg, 10 if args.config == 3 else 1, kk["hbm_read_bytes"] / 1e9, kk["hbm_written_bytes"] / 1e9,
                                              pm["calibration"]["true_bytes_per_counted_read_byte"],
                                              pm["calibration"]["true_bytes_per_counted_written_byte"]))
-            for name in (() if traffic else ("r05_k1_pmc_traffic.json", "r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
+            for name in (() if traffic else ("r06_k1_pmc_traffic.json", "r05_k1_pmc_traffic.json", "r04_k1_pmc_traffic.json", "r03_k1_pmc_traffic.json", "r02_k1_pmc_traffic.json", "r01_k1_pmc_traffic.json")):
                 tf = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tf):
                     jd = json.load(open(tf))
