@@ -28,7 +28,7 @@ import time
 # a queue serialise.  With the GPU to itself this benchmark gains 1-3 % from sixteen (GPU_MAX_HW_QUEUES=16 python
 # bench.py: 221 -> 215 ms per configs[2] step in two calls, 220 -> 218 in a third), but more than sixteen queues on one
 # device IN TOTAL take turns (24 in one process: 290-357 ms; this process' sixteen plus the sixteen of the
-# per_rank_share_of_8 child: 289 ms for the child), so the default is left alone.
+# per_rank_share_of_8 child: 289 ms for the child), so the default is left alone (docs/HISTORY.md section 4).
 import numpy as np
 import torch
 
@@ -354,7 +354,7 @@ def child_bench(args, config, steps, warmup, inflight=None, cpu_share=None, spaw
     cmd = [sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", str(steps), "--warmup", str(warmup),
            "--no-cpu-baseline", "--no-secondary", "--no-tertiary", "--no-pmc", "--no-share-block", "--no-reference-case",
            "--no-ceilings", "--no-shard-block", "--no-host-entry", "--no-hashtable-block", "--no-kernel-roofline",
-           "--no-warm-extra", "--rotate", str(args.rotate)]
+           "--no-warm-extra"] + (["--rotate", str(args.rotate)] if args.rotate else [])
     if inflight:
         cmd += ["--inflight", str(inflight)]
     if cpu_share:
@@ -666,10 +666,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 --pmc passes (about 40 s); read it from profiles/")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region")
-    ap.add_argument("--rotate", type=int, default=3,
+    ap.add_argument("--rotate", type=int, default=None,
                     help="distinct resident batches (other seeds, every signal its own message) a lane rotates through from step "
-                         "to step, so that no step finds the previous one's messages in the host's message cache; 1 = the "
-                         "round-5 shape (ONE batch of 7 600 possible messages decoded on every step: a warm cache)")
+                         "to step, so that no step finds the previous one's messages in the host's message cache (default: 3, "
+                         "or as many as it takes for 24 576 distinct messages -- the cache holds 20 000 -- i.e. 24 batches of "
+                         "1 024 single-signal segments); 1 = the round-5 shape (ONE batch of 7 600 possible messages "
+                         "decoded on every step: a warm cache)")
     ap.add_argument("--no-warm-extra", action="store_true",
                     help="skip the labelled extra 'warm_cache' (the round-5 shape measured beside the cold figure)")
     ap.add_argument("--fano-fast", type=int, default=None,
@@ -780,7 +782,9 @@ def main():
         decode different batches.  warm=True: ONE batch of synth.message_for texts on every step (the round-5 shape)."""
         fast_old = None
         inflight = lanes_primary if config == args.config else (min(args.inflight, 6) if args.inflight else default_inflight(config))
-        nrot = 1 if (config == 5 or warm) else max(1, args.rotate)
+        nsig_of = {2: 1, 3: 10, 4: 1, 5: 1}[config]
+        auto_rot = min(32, max(3, -(-24576 // max(1, nseg * nsig_of))))          # more distinct messages than the cache holds
+        nrot = 1 if (config == 5 or warm) else max(1, args.rotate if args.rotate else auto_rot)
         wide = nrot > 1
         batches = []                                     # [(I, Q, expected)]: the distinct batches a lane rotates through
         if config in (2, 4):
@@ -943,7 +947,7 @@ def main():
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
     lap("headline (synthesis, untimed and timed steps)")
     warm_extra = None
-    if not args.no_warm_extra and args.config != 5 and args.rotate > 1:
+    if not args.no_warm_extra and args.config != 5 and args.rotate != 1:
         # the round-5 shape beside the cold figure (labelled extra, never `value`): ONE batch of synth.message_for texts
         # decoded on every step, so every message after the first step comes out of the host's per-thread cache
         keep = {k: m[k] for k in ("I", "Q")}

@@ -5,7 +5,7 @@
  * libwspr_mi355x_lab.so -- the same sources, kernels and scheduler plus what is declared here, plus the environment
  * switches that select alternative kernels or repeat stages (WSPR_K0_KERNEL, WSPR_K0_RESIDENT, WSPR_K0_CUS,
  * WSPR_K1_FUSED, WSPR_K3_KERNEL, WSPR_K4_LAG, WSPR_K4_FREQ, WSPR_K4_DRIFT, WSPR_REPEAT_LAG / _FREQ / _FANO,
- * WSPR_FANO_WAVE_CAP, WSPR_NODE_VIRTUAL; DESIGN.md section 4 "Switches"), which read as unset in the product.
+ * WSPR_FANO_WAVE_CAP, WSPR_NODE_VIRTUAL; docs/HISTORY.md section 4 "Switches"), which read as unset in the product.
  * tests/ and bench.py load the lab library for these calls and the product library for everything else.
  * ==========================================================================*/
 #ifndef WSPR_MI355X_BENCH_H

@@ -1139,7 +1139,7 @@ void launch_freq_scan_and_first_rung(const float* dI, const float* dQ, int sampl
     // the centre hypothesis is read from it instead of being summed again; pw must then be a different buffer
     const float4* pl = reinterpret_cast<const float4*>(pw_lag);
     // WSPR_REPEAT_FREQ / _LAG / _FANO = 2: the stage's kernels are launched twice (same outputs) -- what a stage costs
-    // INSIDE the pipelined step is the difference of two bench lines
+    // INSIDE the pipelined step is the difference of two bench lines (docs/HISTORY.md section 4)
     static const int rep_freq = [] { const char* e = lab_env("WSPR_REPEAT_FREQ"); return e ? std::max(1, atoi(e)) : 1; }();
     // WSPR_K4_FREQ=nocentre: no centre hypothesis is taken from the lag scan (every candidate through the rare path)
     static const bool nocentre = [] { const char* e = lab_env("WSPR_K4_FREQ"); return e && e[0] == 'n'; }();
