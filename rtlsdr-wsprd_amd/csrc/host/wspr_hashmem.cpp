@@ -107,15 +107,15 @@ const char* SegHashView::call_at(int slot) {
     const char* c = hb.lookup(slot, hb.seg0 + s);
     HashOp op{};
     op.seg = hb.seg0 + s; op.slot = slot; op.kind = 3;
-    snprintf(op.call, sizeof op.call, "%s", c);
+    copy_text(op.call, sizeof op.call, c);
     hb.log[(size_t)s].push_back(op);
     return c;                                   // base / version storage: unchanged for the whole round
 }
 void SegHashView::put(int slot, const char* call, const char* grid) {
     HashOp op{};
     op.seg = hb.seg0 + s; op.slot = slot; op.kind = grid ? 1 : 2;
-    snprintf(op.call, sizeof op.call, "%s", call);
-    if (grid) snprintf(op.grid, sizeof op.grid, "%s", grid);
+    copy_text(op.call, sizeof op.call, call);
+    if (grid) copy_text(op.grid, sizeof op.grid, grid);
     hb.log[(size_t)s].push_back(op);
 }
 
@@ -130,8 +130,8 @@ struct RecordingTable : HashTable {
     void put(int slot, const char* call, const char* grid) override {
         MessageCache::Put p{};
         p.slot = slot; p.has_grid = grid != nullptr;
-        snprintf(p.call, sizeof p.call, "%s", call);
-        if (grid) snprintf(p.grid, sizeof p.grid, "%s", grid);
+        copy_text(p.call, sizeof p.call, call);
+        if (grid) copy_text(p.grid, sizeof p.grid, grid);
         puts.push_back(p);
         t.put(slot, call, grid);
     }

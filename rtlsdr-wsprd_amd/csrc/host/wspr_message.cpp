@@ -378,8 +378,8 @@ struct QuietView : HashTable {
 }  // namespace
 
 void FlatHashTable::put(int slot, const char* call, const char* grid) {
-    std::snprintf(hashtab + (size_t)slot * kHashWidth, kHashWidth, "%s", call);
-    if (grid) std::snprintf(loctab + (size_t)slot * kLocWidth, kLocWidth, "%s", grid);
+    copy_text(hashtab + (size_t)slot * kHashWidth, kHashWidth, call);
+    if (grid) copy_text(loctab + (size_t)slot * kLocWidth, kLocWidth, grid);
     if (dirty_vec) static_cast<std::vector<int>*>(dirty_vec)->push_back(slot);
 }
 

@@ -18,6 +18,15 @@ constexpr int kHashSlots = 32768;
 constexpr int kHashWidth = 13;
 constexpr int kLocWidth = 5;
 
+// snprintf(dst, cap, "%s", src) without the format machinery: at most cap - 1 characters and the terminating NUL, nothing
+// beyond it touched (the per-decode bookkeeping copies a dozen short texts; 70 ns each through snprintf)
+inline void copy_text(char* dst, size_t cap, const char* src) {
+    if (cap == 0) return;
+    size_t i = 0;
+    for (; i + 1 < cap && src[i] != '\0'; ++i) dst[i] = src[i];
+    dst[i] = '\0';
+}
+
 // sync vector (wsprd/wsprd.c:84-93) as bytes 0/1
 const unsigned char* sync_vector();
 

@@ -832,7 +832,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         for (int u = 0; u < bk.uniques; ++u)
             if (!strcmp(callsign, bk.allcalls[u]) && fabs(w.fine.freq - bk.allfreqs[u]) < 3.0) dupe = true;
         if (dupe || bk.uniques >= 100) continue;
-        snprintf(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], "%s", callsign);
+        copy_text(bk.allcalls[bk.uniques], sizeof bk.allcalls[0], callsign);
         bk.allfreqs[bk.uniques] = w.fine.freq;
         bk.uniques++;
         {
@@ -849,10 +849,10 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
             o->drift = w.fine.drift;
             o->cycles = (int)w.cycles;
             o->jitter = w.jitter;
-            snprintf(o->message, sizeof o->message, "%s", call_loc_pow);
-            snprintf(o->call, sizeof o->call, "%s", call);
-            snprintf(o->loc, sizeof o->loc, "%s", loc);
-            snprintf(o->pwr, sizeof o->pwr, "%s", pwr);
+            copy_text(o->message, sizeof o->message, call_loc_pow);       // snprintf(.., "%s", ..) of wsprd.c:817-820
+            copy_text(o->call, sizeof o->call, call);
+            copy_text(o->loc, sizeof o->loc, loc);
+            copy_text(o->pwr, sizeof o->pwr, pwr);
         }
       }
       if (lockstep) win[sg] = cut ? 1 : std::min(64, 2 * win[sg]);
