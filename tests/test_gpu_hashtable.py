@@ -285,8 +285,9 @@ def test_revisit_is_refused_when_its_state_is_gone(w, tmp_path):
     ex = ThreadPoolExecutor(1)
     ex.submit(L.wspr_bind_thread_lane, 5).result()
 
+    out = (w.decoder_results * (nseg * K))(); nres = (C.c_int * nseg)()      # a revisit rewrites only what it decodes again
+
     def call(flags, prior=None):
-        out = (w.decoder_results * (nseg * K))(); nres = (C.c_int * nseg)()
         st = np.zeros((64 * nseg, 32), np.uint8); n_st = C.c_int(0)
         pr = np.ascontiguousarray(prior if prior is not None else np.zeros((0, 32), np.uint8))
         rc = L.wspr_decode_batch_hashed(ol.ptr(I), ol.ptr(Q), nseg, NS, NS, _opt(w, 1), C.addressof(out), K, C.addressof(nres), 0,
