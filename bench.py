@@ -947,7 +947,7 @@ def main():
     m = measure(args.config, nseg, args.steps, args.warmup, rank)
     lap("headline (synthesis, untimed and timed steps)")
     warm_extra = None
-    if not args.no_warm_extra and args.config != 5 and args.rotate != 1:
+    if not args.no_warm_extra and args.config != 5 and args.rotate != 1 and world == 1 and not use_dist:
         # the round-5 shape beside the cold figure (labelled extra, never `value`): ONE batch of synth.message_for texts
         # decoded on every step, so every message after the first step comes out of the host's per-thread cache
         keep = {k: m[k] for k in ("I", "Q")}
