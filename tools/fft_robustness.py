@@ -151,6 +151,46 @@ def ps_perturbation(segs, variants):
     return out
 
 
+def detail(a):
+    L = ol.lib()
+    wl = a.workloads.split(",")[0]
+    if wl == "c1":
+        segs = gen_c1(a.n_c1)
+    elif wl == "c2":
+        with ThreadPoolExecutor(a.threads) as ex:
+            segs = list(ex.map(gen_c2_one, range(a.n_c2)))
+    else:
+        segs = gen_scenes(a.n_scenes)
+
+    def run(k):
+        I, Q = segs[k]
+        spots, _, _, tr = ol.decode(I, Q, NS, trace=True)
+        cands = [[(round(tr.cand_peaks[p][i].freq, 4), round(tr.cand_peaks[p][i].snr, 4), tr.decoded[p][i])
+                  for i in range(tr.npk[p])] for p in range(tr.passes_run)]
+        return [spot_rec(s) for s in spots], cands, [float(tr.noise_level[p]) for p in range(tr.passes_run)]
+    out = {}
+    for v in (0, a.detail):
+        L.orc_set_fft_variant(v)
+        with ThreadPoolExecutor(a.threads) as ex:
+            out[v] = list(ex.map(run, range(len(segs))))
+    L.orc_set_fft_variant(0)
+    n = 0
+    for k, (b, v) in enumerate(zip(out[0], out[a.detail])):
+        differs = len(b[0]) != len(v[0]) or any(x[:4] != y[:4] or x[5:] != y[5:] or abs(x[4] - y[4]) > 1e-3 for x, y in zip(b[0], v[0]))
+        if not differs:
+            continue
+        n += 1
+        print("segment %d (%s): noise level per pass %r vs %r" % (k, wl, b[2], v[2]))
+        for x, y in zip(b[0], v[0]):
+            if x != y:
+                print("   spot  variant 0:", x, "\n         variant %d:" % a.detail, y)
+        for p in range(min(len(b[1]), len(v[1]))):
+            if b[1][p] != v[1][p]:
+                print("   pass %d candidates (freq, snr, decoded), variant 0: %r" % (p, b[1][p]))
+                print("   pass %d candidates (freq, snr, decoded), variant %d: %r" % (p, a.detail, v[1][p]))
+    print("%d of %d segments differ beyond the SNR's last digits" % (n, len(segs)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="c1,c2,scenes")
@@ -160,7 +200,13 @@ def main():
     ap.add_argument("--n-scenes", type=int, default=3000)
     ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_fft_robustness.json"))
+    ap.add_argument("--detail", type=int, default=None,
+                    help="instead of the study: decode the (single) workload with variant 0 and with this variant and print, for "
+                         "every segment whose spots differ in anything but the SNR's last digits, both spot lists and both "
+                         "passes' candidate lists (which decision flipped)")
     a = ap.parse_args()
+    if a.detail is not None:
+        return detail(a)
     variants = [int(x) for x in a.variants.split(",") if x]
     L = ol.lib()
     result = {"tolerances": TOL, "variants": {str(v): VARIANT_NAMES[v] for v in [0] + variants}, "workloads": {},
