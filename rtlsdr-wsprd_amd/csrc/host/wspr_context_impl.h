@@ -243,7 +243,7 @@ struct Context::Impl {
     char* hash_arena = nullptr;
     size_t hash_arena_segs = 0;
     double t_ms[26] = {0};           // stage times (ms), Fano statistics and host CPU time by phase of the last batch
-    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0};
+    std::atomic<long> n_fano{0}, n_timeout{0}, n_cycles{0}, n_kept{0}, n_subjobs{0}, n_mc_lookups{0}, n_mc_hits{0};
     bool blocking = false;
     hipEvent_t ev_sync = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};

@@ -213,7 +213,7 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
                              wspr_trace* trace, HashBatch* hb, int hb_off) {
     Impl& c = *d;
     for (double& v : c.t_ms) v = 0.0;
-    c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0;
+    c.n_fano = 0; c.n_timeout = 0; c.n_cycles = 0; c.n_kept = 0; c.n_subjobs = 0; c.n_mc_lookups = 0; c.n_mc_hits = 0;
     const auto t_all0 = std::chrono::steady_clock::now();
     CpuSpan cpu_all(&c.t_ms[16]);
     t_spin_us = nseg <= 128 ? 600 : 40;      // a call of up to a hundred segments is a few milliseconds: its waits poll (lone 17-127-segment calls: 1.7-2.8 -> 1.3-2.3 ms)
@@ -272,6 +272,8 @@ int Context::decode_resident(int nseg, int samples, const decoder_options& opt, 
     c.t_ms[9] = (double)c.n_cycles.load();
     c.t_ms[14] = (double)c.n_kept.load();                 // refined candidates whose result was consumed (the rest: cut speculation)
     c.t_ms[15] = (double)c.n_subjobs.load();
+    c.t_ms[24] = (double)c.n_mc_lookups.load();           // the books are kept by the pool's threads: atomic counts
+    c.t_ms[25] = (double)c.n_mc_hits.load();
     c.crowded = c.n_timeout.load() * 10 > nseg;
     return 0;
 }
@@ -811,7 +813,7 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         MessageCache& mc = MessageCache::of_this_thread();
         const unsigned long mc_hits0 = mc.hits;
         MessageCache::Handle mh = mc.unpack(w.decdata, tab, call_loc_pow, call, loc, pwr, callsign);
-        c.t_ms[24] += 1.0; c.t_ms[25] += (double)(mc.hits - mc_hits0);     // message-cache look-ups and hits of this call
+        c.n_mc_lookups++; c.n_mc_hits += (long)(mc.hits - mc_hits0);       // message-cache look-ups and hits of this call
         const int noprint = mh.noprint;
         auto symbols_of = [&](unsigned char* sym) { return mc.symbols(mh, call_loc_pow, tab, sym); };
         if (opt.subtraction && ipass == 0 && !noprint) {
