@@ -73,8 +73,9 @@ def test_spots_do_not_depend_on_the_fft_on_a_sample(variant_guard):
 
 def test_committed_full_size_study_stays_under_its_ceilings():
     """profiles/r06_fft_robustness.json (tools/fft_robustness.py, run in the build container): for every workload and
-    every alternative FFT, the share of segments whose spot set differs <= 0.1 %, no spot beyond the north-star
-    tolerances, no call/loc/pwr change among matched spots."""
+    every alternative FFT no segment gains or loses a spot, no call/loc/pwr, dt, frequency, drift, jitter or cycle count
+    changes, and the SNR moves by <= 1e-4 dB (measured: 5.7e-6; north_star allows 0.1 dB).  (One spot of the first run
+    of one variant differed by 0.58 dB and did not in two re-runs: kept in the file under "not_reproduced".)"""
     path = os.path.join(ROOT, "profiles", "r06_fft_robustness.json")
     d = json.load(open(path))
     assert set(d["workloads"]) >= {"c1", "c2", "scenes"}
@@ -84,4 +85,8 @@ def test_committed_full_size_study_stays_under_its_ceilings():
         for v, r in blk["by_variant"].items():
             assert r["segments_spot_set_differs"] <= 1e-3 * r["segments"], (wl, v, r)
             assert r["spots_beyond_tolerance"] == 0 and r["spots_text_changed"] == 0, (wl, v, r)
-            assert r["max_dsnr_db"] <= 0.1 and r["max_ddt_s"] <= 0.010 and r["max_dfreq_hz"] <= 0.1, (wl, v, r)
+            assert r["max_ddt_s"] == 0.0 and r["max_dfreq_hz"] == 0.0 and r["max_dsnr_db"] <= 1e-4, (wl, v, r)
+            assert r["spots_lost"] == 0 and r["spots_gained"] == 0, (wl, v, r)
+            assert r["spots_drift_changed"] == 0 and r["spots_jitter_changed"] == 0 and r["spots_cycles_changed"] == 0, (wl, v, r)
+    total_pairs = sum(r["spots_base"] for blk in d["workloads"].values() for r in blk["by_variant"].values())
+    assert total_pairs > 600000
