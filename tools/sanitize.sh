@@ -32,8 +32,8 @@ if [ "$cmd" = build ]; then
   done
   for p in "${pids[@]}"; do wait "$p"; done
   $HIPCC --offload-arch=gfx950 -shared -fPIC ${SAN/-fno-gpu-sanitize/} -shared-libsan -o "$out/libwspr_mi355x_lab.so" "$out"/*.o -lpthread
-  $CXX -O1 -g -std=c++17 -fno-omit-frame-pointer ${SAN/-fno-gpu-sanitize/} -shared-libsan "$root/tools/sanitize_driver.cpp" \
-       -L"$out" -lwspr_mi355x_lab -Wl,-rpath,"$out" -Wl,-rpath,"$rt" -lpthread -o "$out/driver"
+  $CXX -O1 -g -std=c++17 -fno-omit-frame-pointer ${SAN/-fno-gpu-sanitize/} -shared-libsan -I/opt/rocm/include "$root/tools/sanitize_driver.cpp" \
+       -L"$out" -lwspr_mi355x_lab -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,"$out" -Wl,-rpath,"$rt" -lpthread -o "$out/driver"
   echo "built $out/driver"
 else
   mode="${3:-host}"; nseg="${4:-384}"

@@ -6,6 +6,9 @@
 // three RX threads and decoded together, three threads sharing lane 0, the node-level
 // call folded onto lanes, buffer release.  "host" = the part that needs no GPU (message layer, file formats, hash file).
 // Every check is a plain comparison; the sanitizers report on their own.
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -258,6 +261,51 @@ static void gpu_part(int nseg) {
         CHECK(wspr_bind_thread_lane(0) == 0);
         CHECK(wspr_decode_batch_node(I.data(), Q.data(), nseg, NS, NS, options(), rn.data(), 8, nn.data(), 3) == 0);
         CHECK(nn == n0 && memcmp(rn.data(), r0.data(), r0.size() * sizeof(decoder_results)) == 0);
+    }
+    // 6. (round 6) a -H shard whose store buffer is too small: -3, nothing committed; completed by a revisit; a revisit whose
+    //    rows are gone (buffers released) must be refused, not write through a dangling pointer
+    {
+        const int nh = 32;
+        std::vector<float> HI((size_t)nh * NS), HQ((size_t)nh * NS);
+        for (int s = 0; s < nh; ++s)
+            make_segment(s % 2 == 1 ? "PJ4/K1ABC 37" : "<PJ4/K1ABC> FK52UD 37", 20.0, 2.0, -8.0, 1900 + s, HI.data() + (size_t)s * NS,
+                         HQ.data() + (size_t)s * NS);
+        unlink("hashtable.txt");
+        std::vector<decoder_results> rh((size_t)nh * 8);
+        std::vector<int> nr(nh);
+        std::vector<wspr_hash_op> st(4 * nh + 64);
+        int n_st = 0, n_re = 0;
+        CHECK(wspr_decode_batch_hashed(HI.data(), HQ.data(), nh, NS, NS, options(1), rh.data(), 8, nr.data(), 0, 10, nullptr, 0,
+                                       WSPR_HASH_KEEP_FILE, st.data(), 1, &n_st, &n_re) == -3);
+        CHECK(n_st > 1 && access("hashtable.txt", F_OK) != 0);
+        CHECK(wspr_decode_batch_hashed(HI.data(), HQ.data(), nh, NS, NS, options(1), rh.data(), 8, nr.data(), 0, 10, nullptr, 0,
+                                       WSPR_HASH_KEEP_FILE | WSPR_HASH_REVISIT, st.data(), (int)st.size(), &n_st, &n_re) == 0);
+        wspr_hash_op fake;
+        memset(&fake, 0, sizeof fake);
+        fake.seg = 5; fake.slot = (int)(nhash("PJ4/K1ABC", 9, 146)); fake.kind = 2; snprintf(fake.call, sizeof fake.call, "PJ4/K1ABC");   // segment 10 (a hashed call, unresolved so far) now resolves: it must be decoded again
+        wspr_release_buffers();
+        CHECK(wspr_decode_batch_hashed(HI.data(), HQ.data(), nh, NS, NS, options(1), rh.data(), 8, nr.data(), 0, 10, &fake, 1,
+                                       WSPR_HASH_KEEP_FILE | WSPR_HASH_REVISIT, st.data(), (int)st.size(), &n_st, &n_re) < 0);
+        unlink("hashtable.txt");
+    }
+    // 7. (round 6) the node-level call on resident rows: peer copies made to fail (the staged copy takes over), one shard
+    //    made to fail (the whole call fails and reports nothing)
+    {
+        float *dI = nullptr, *dQ = nullptr;
+        const size_t bytes = (size_t)nseg * NS * 4;
+        CHECK(hipMalloc((void**)&dI, bytes) == hipSuccess && hipMalloc((void**)&dQ, bytes) == hipSuccess);
+        CHECK(hipMemcpy(dI, I.data(), bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dQ, Q.data(), bytes, hipMemcpyHostToDevice) == hipSuccess);
+        std::vector<int> nn(nseg);
+        std::vector<decoder_results> rn((size_t)nseg * 8);
+        setenv("WSPR_NODE_FAIL_PEER", "1", 1);
+        CHECK(wspr_decode_batch_node_device(dI, dQ, 0, nseg, NS, NS, options(), rn.data(), 8, nn.data(), 3) == 0);
+        CHECK(nn == n0 && memcmp(rn.data(), r0.data(), r0.size() * sizeof(decoder_results)) == 0);
+        unsetenv("WSPR_NODE_FAIL_PEER");
+        setenv("WSPR_NODE_FAIL_SHARD", "2", 1);
+        CHECK(wspr_decode_batch_node_device(dI, dQ, 0, nseg, NS, NS, options(), rn.data(), 8, nn.data(), 3) < 0);
+        CHECK(std::all_of(nn.begin(), nn.end(), [](int v) { return v == 0; }));
+        unsetenv("WSPR_NODE_FAIL_SHARD");
+        (void)hipFree(dI); (void)hipFree(dQ);
     }
     printf("released %zu bytes\n", wspr_release_buffers());
 }
