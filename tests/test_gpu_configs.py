@@ -351,21 +351,25 @@ def test_bench_gpus_flag_spawns_its_own_rank_over_rccl():
     assert f["segments_scattered_from_rank0"] == 4 and f["equal_to_rank0_own_decode"] == "4/4"
 
 
-def test_bench_gpus_2_spawns_two_ranks_sharing_the_one_gpu():
+@pytest.mark.parametrize("config", ["2", "3"])
+def test_bench_gpus_2_spawns_two_ranks_sharing_the_one_gpu(config):
     """`python bench.py --gpus 2`: two ranks really start, see each other, split the host's CPUs, each decodes its own
     batch, rank 0 scatters eight of ITS segments over both ranks and gets the same spots back, and prints n_gpus 2
     with the aggregate rate.  On this 1-GPU box the two ranks share the device and the collectives run on gloo (RCCL
     refuses two ranks on one device) -- everything else is the code the 2/4/8-GPU runs execute."""
-    d = _bench_line(["--gpus", "2", "--config", "2", "--segments", "256", "--steps", "6", "--warmup", "2",
-                     "--no-cpu-baseline", "--min-seconds", "0"],
+    # (config 3 = the driver's own default, the headline workload, at 1/32 of its size: ten signals per segment, the device
+    # Fano search, 32 spots per segment in the gathered records)
+    d = _bench_line(["--gpus", "2", "--config", config, "--segments", "256", "--steps", "6", "--warmup", "2",
+                     "--no-cpu-baseline", "--min-seconds", "0", "--no-kernel-roofline"],
                     _no_launcher_env(WSPR_BENCH_SHARE_GPU="1", WSPR_BENCH_BACKEND="gloo", WSPR_HOST_THREADS="2"))
     ok, sent = map(int, d["decoded_ok"].split("/"))
-    assert d["n_gpus"] == 2 and ok >= 0.95 * sent and d["false_decodes"] == 0
+    assert d["n_gpus"] == 2 and ok >= (0.95 if config == "2" else 0.9) * sent and d["false_decodes"] == 0
+    assert sent == (256 if config == "2" else 2560) and len(d["ranks"]) == 2
     # the line says that the two ranks sat on ONE device (round-3 advisor finding), and a rank with the CPU share of an
     # 8-rank job (2 of these boxes' 16 CPUs) adds no pool threads to the lane threads that drive its batches
     assert d["distinct_devices"] == 1 and d["devices_shared"] is True
     assert d["host_threads"] == 2 and d["host_pool_workers"] == 0
-    assert d["config"]["segments_per_gpu"] == 256 and d["spots_total"] >= 2 * ok - 4        # both ranks' records arrived
+    assert d["config"]["segments_per_gpu"] == 256 and d["spots_total"] >= (2 * ok - 4 if config == "2" else 1.9 * ok)   # both ranks' records arrived
     assert d["fanout_check"]["segments_scattered_from_rank0"] == 8
     assert d["fanout_check"]["equal_to_rank0_own_decode"] == "8/8"
     assert d["value"] > 0 and d["scaling"] == "weak"
