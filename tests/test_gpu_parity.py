@@ -388,6 +388,37 @@ def test_randomised_scenes_equal_oracle(w):
     assert total > 40 and len(got[0]) == 0
 
 
+def test_messages_from_the_whole_type1_space_equal_oracle(w):
+    """Round 6: the benchmark's signals carry messages drawn from the whole type-1 space (synth.message_wide: four-,
+    five- and six-character calls of both packing shapes, every locator field, every power) instead of twenty calls x
+    twenty grids.  64 segments x 3 such signals: every field of every spot equals the oracle's, and what is decoded is
+    what was sent (the unpack / re-encode path written by hand in round 6 sits under every one of these spots)."""
+    rng = np.random.default_rng(606)
+    sigma = np.sqrt((375.0 / 2500.0) / 2.0)
+    Is, Qs, sent = [], [], []
+    for s in range(64):
+        I = rng.normal(0, sigma, NS); Q = rng.normal(0, sigma, NS)
+        msgs = [synth.message_wide(int(rng.integers(0, 1 << 62))) for _ in range(3)]
+        for k, m in enumerate(msgs):
+            si, sq = synth.tone_signal(symf(m), -80.0 + 80.0 * k + rng.uniform(-3, 3), rng.uniform(1.7, 2.3), 10.0 ** ((-9.0 - 3 * k) / 20.0))
+            I += si; Q += sq
+        a, b = synth.normalise(I.astype(np.float32), Q.astype(np.float32))
+        Is.append(a); Qs.append(b); sent.append([synth.expected_text(m) for m in msgs])
+    I = np.stack(Is); Q = np.stack(Qs)
+    got = w.wspr_decode_batch(I, Q, w.default_options())
+    hits = 0
+    for s in range(64):
+        ref, _, _ = ol.decode(I[s], Q[s], NS)
+        assert [_spot_tuple(x) for x in got[s]] == [_spot_tuple(x) for x in ref], s
+        assert all(abs(a.snr - b.snr) < 1e-4 for a, b in zip(got[s], ref))
+        texts = [x.message.decode() for x in got[s]]
+        assert all(t in sent[s] for t in texts), (s, texts, sent[s])          # no false decode
+        hits += len(set(texts) & set(sent[s]))
+    assert hits >= 0.95 * 3 * 64
+    shapes = {len(t.split()[0]) for seg in sent for t in seg}
+    assert shapes >= {4, 5, 6}
+
+
 def crowded_scenes(count, seed=77):
     """Bands the other generators do not produce: 12-40 signals inside +-112 Hz (many closer than one tone
     spacing), -24..+12 dB, so that a segment yields dozens of candidates, repeated decodes of one signal and
