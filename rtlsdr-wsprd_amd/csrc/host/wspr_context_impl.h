@@ -195,11 +195,35 @@ private:
 };
 
 // ---------------------------------------------------------------- context ----
+// The callsign hash memory of ONE segment without usehashtable: the reference's locals hashtab[32768][13] / loctab[32768][5]
+// (wsprd.c:478-479), zeroed for every call, of which a segment's decodes touch a handful of slots -- kept as the list of
+// slots written instead of 590 KB per segment (8 192 segments: 4.8 GB of arena per context, and four cache misses per
+// decode into it; round 6).  Same answers: a look-up returns the last call stored at the slot, "" if none; the locator
+// table is never read without the option (it only goes to hashtable.txt), so it is not kept.
+struct SparseHashTable : wspr::HashTable {
+    struct Entry { int slot; char call[wspr::kHashWidth]; };
+    std::vector<Entry> entries;
+    const char* find(int slot) const {
+        for (size_t i = entries.size(); i-- > 0;) if (entries[i].slot == slot) return entries[i].call;
+        return "";
+    }
+    const char* call_at(int slot) override { return find(slot); }
+    const char* peek(int slot) override { return find(slot); }
+    void put(int slot, const char* call, const char*) override {
+        for (Entry& e : entries) if (e.slot == slot) { wspr::copy_text(e.call, sizeof e.call, call); return; }
+        Entry e;
+        e.slot = slot;
+        wspr::copy_text(e.call, sizeof e.call, call);
+        entries.push_back(e);
+    }
+};
+
 struct SegBook {                 // host bookkeeping of one segment across passes
     int   uniques = 0;
     float allfreqs[100];
     char  allcalls[100][13];
-    std::vector<int> dirty;      // hash slots written (cleared when the batch ends)
+    SparseHashTable hash;        // the segment's hash memory (cleared when the batch ends); usehashtable: flat arena / HashBatch
+    std::vector<int> dirty;      // hash slots written in the flat arena (single call with usehashtable)
     std::vector<decoder_results> spots;   // every unique spot, in decode order (the reference's 100 at most)
 };
 

@@ -350,11 +350,13 @@ struct Context::DecodeRun {
           nlag0(256 / (opt_.quickmode ? 16 : 8) + 1), njit_rest(opt_.quickmode ? 0 : kMaxLags - 1), book(ctx_.d->books),
           npk(ctx_.d->npk_host), cand(ctx_.d->cand_host), persist(opt_.usehashtable && nseg_ == 1) {
         if (book.size() < (size_t)nseg) book.resize((size_t)nseg);
-        if (c.hash_arena_segs < (size_t)nseg) {
+        // the flat table pair exists for the one case that reads and writes hashtable.txt itself: a single call with
+        // usehashtable (segment 0); every other segment keeps the slots it wrote (SegBook::hash)
+        if (persist && c.hash_arena_segs < 1) {
             free(c.hash_arena);
-            c.hash_arena = static_cast<char*>(calloc((size_t)nseg, per_seg));
+            c.hash_arena = static_cast<char*>(calloc(1, per_seg));
             if (!c.hash_arena) throw std::runtime_error("out of host memory for hash tables");
-            c.hash_arena_segs = (size_t)nseg;
+            c.hash_arena_segs = 1;
         }
     }
     char* hashtab_of(int s) const { return c.hash_arena + (size_t)s * per_seg; }
@@ -806,9 +808,9 @@ std::vector<SubJob> Context::DecodeRun::keep_books(std::vector<WaveItem>& wave) 
         SegBook& bk = book[s];
         // the segment's hash memory: its own zeroed tables (the reference's locals, wsprd.c:478-479; every slot written
         // is noted and cleared again when the batch ends), or its window on the batch's shared memory (usehashtable)
-        FlatHashTable flat(hashtab_of(s), loctab_of(s), &bk.dirty);
+        FlatHashTable flat(persist ? hashtab_of(s) : nullptr, persist ? loctab_of(s) : nullptr, &bk.dirty);
         std::unique_ptr<SegHashView> shared(hb ? new SegHashView(hb, hb_off + s) : nullptr);
-        HashTable& tab = hb ? static_cast<HashTable&>(*shared) : static_cast<HashTable&>(flat);
+        HashTable& tab = hb ? static_cast<HashTable&>(*shared) : (persist ? static_cast<HashTable&>(flat) : static_cast<HashTable&>(bk.hash));
         // (what the bits unpack and re-encode to is computed once per host thread: MessageCache, wspr_hashmem.h)
         MessageCache& mc = MessageCache::of_this_thread();
         const unsigned long mc_hits0 = mc.hits;
@@ -897,13 +899,7 @@ void Context::DecodeRun::subtract(const std::vector<SubJob>& jobs) {
 // spots, never a strong one that happened to decode late); hash slots written by the batch are cleared again
 void Context::DecodeRun::clear_hash(const std::vector<int>& segs) {
     if (persist) return;
-    for (int s : segs) {
-        for (int slot : book[s].dirty) {
-            memset(hashtab_of(s) + (size_t)slot * kHashWidth, 0, kHashWidth);
-            memset(loctab_of(s) + (size_t)slot * kLocWidth, 0, kLocWidth);
-        }
-        book[s].dirty.clear();
-    }
+    for (int s : segs) { book[s].hash.entries.clear(); book[s].dirty.clear(); }
 }
 
 void Context::DecodeRun::finish(const std::vector<int>& active0, int* n_results) {
@@ -927,7 +923,7 @@ int Context::decode_core(int nseg, int samples, const decoder_options& opt, deco
                          const FanoMemo* memo, wspr_trace* trace, HashBatch* hb, int hb_off) {
     for (int s : active0) n_results[s] = 0;
     DecodeRun run(*this, nseg, samples, opt, out, max_results, fast, pend);
-    for (int s : active0) { SegBook& b = run.book[s]; b.uniques = 0; b.dirty.clear(); b.spots.clear(); }
+    for (int s : active0) { SegBook& b = run.book[s]; b.uniques = 0; b.dirty.clear(); b.hash.entries.clear(); b.spots.clear(); }
     run.memo = memo;
     run.trace = trace;
     run.hb = hb;
